@@ -1,0 +1,134 @@
+/*
+ * loraine_hip.h -- C ABI of libloraine_hip.so, the MI355X (gfx950) implementation of the
+ * per-IP-iteration linear-algebra hot path of Loraine.jl v0.2.5.
+ *
+ * The reference has no FFI layer: the boundary is the set of plain Julia calls made by
+ * myIPstep / predictor / corrector (src/Solvers.jl:448-478, src/predictor_corrector.jl).
+ * Each entry point below names the reference call it replaces (file:line relative to the
+ * reference checkout).  INTEGRATION.md shows the Julia `ccall` glue that binds them.
+ *
+ * Conventions
+ *   - return 0 = OK; negative = API / HIP error (text from lrn_last_error);
+ *     numerical failure is reported LAPACK-style through `info` out-parameters so the host
+ *     can replay the reference's regularisation loops (prepare_W.jl:12-24,
+ *     predictor_corrector.jl:59-85).
+ *   - FP64, column-major, sparse data in the reference's own format: SparseMatrixCSC
+ *     (colptr, rowval, nzval), Int64, 1-based.
+ *   - every data pointer may be HOST or DEVICE memory (detected per call); the caller owns
+ *     it and it is only accessed during the call.  Device state is owned by the context.
+ *   - one context per GPU / per process; calls are blocking and not re-entrant
+ *     (the reference is single-threaded).
+ */
+#ifndef LORAINE_HIP_H
+#define LORAINE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lrn_ctx lrn_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int lrn_create(lrn_ctx** out, int device);
+int lrn_destroy(lrn_ctx* ctx);
+const char* lrn_last_error(lrn_ctx* ctx);
+int lrn_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int lrn_device_count(void);
+
+/* ---- static model data: the outputs of _prepare_A (src/model.jl:120-150) -------------- */
+/* AA[ilmi]: nvar x msz^2 CSC, row j = -vec(A_j) (model.jl:199-229).
+ * B[ilmi] : nvar x msz CSC rank-one factors (model.jl:176-197) or NULL arrays.
+ * sigmaA  : nvar x nlmi (col-major, 1-based), qA: 2 x nlmi (model.jl:153-174).
+ * C_lin   : nvar x nlin CSC (MOI_wrapper.jl:145-149) or nlin = 0.                        */
+int lrn_upload_model(lrn_ctx* ctx, int nlmi, int nvar, const int64_t* msizes,
+                     const int64_t* const* AA_colptr, const int64_t* const* AA_rowval,
+                     const double* const* AA_nzval,
+                     const int64_t* const* B_colptr, const int64_t* const* B_rowval,
+                     const double* const* B_nzval,
+                     const int64_t* sigmaA, const int64_t* qA,
+                     int nlin, const int64_t* Clin_colptr, const int64_t* Clin_rowval,
+                     const double* Clin_nzval);
+/* Builder-defined synthetic dense SDP data generated on the device:
+ * A_k = (R_k + R_k')/2, R_k iid N(0,1) from a counter-based Philox stream; nlmi = 1. */
+int lrn_synthetic_dense_model(lrn_ctx* ctx, int msz, int nvar, uint64_t seed);
+/* dense copy of constraint matrix A_k (0-based k) of block ilmi, msz x msz */
+int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
+/* tuning knobs: "dense_threshold" (nnz above which a branch-1 constraint takes the MFMA
+ * path), "profile" (0/1), "t_batch", "p_batch". */
+int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
+/* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */
+int lrn_set_shard(lrn_ctx* ctx, int rank, int world);
+
+/* ---- NT scaling: prepare_W (src/prepare_W.jl:28-94) ----------------------------------- */
+/* X, S: msz x msz in; outputs may be NULL (kept on the device only).
+ * info: 0 ok; 1 = X not PD, 2 = S not PD (host adds 1e-5*I and retries, :5-26). */
+int lrn_prepare_w(lrn_ctx* ctx, int ilmi, const double* X, const double* S, double* D, double* G,
+                  double* Gi, double* W, double* Si, double* DDsi, int* info);
+/* directly set W (and optionally G) -- used when the scaling is produced elsewhere */
+int lrn_set_scaling(lrn_ctx* ctx, int ilmi, const double* W, const double* G_or_null);
+/* X_lin .* S_lin_inv for the C_lin terms (predictor_corrector.jl:37, Solvers.jl:609) */
+int lrn_set_lin(lrn_ctx* ctx, const double* X_lin, const double* S_lin_inv);
+
+/* ---- Schur complement: makeBBBBs / makeBBBB_rank1 (src/makeBBBB.jl:1-218) ------------- */
+/* mode 0 = general (makeBBBBs), -1 = rank-one data (makeBBBB_rank1); adds the C_lin term
+ * (predictor_corrector.jl:36-38).  H_out (nvar x nvar) may be NULL; when given it receives
+ * Matrix(Hermitian(BBBB, :L)) (predictor_corrector.jl:39). */
+int lrn_schur_assemble(lrn_ctx* ctx, int mode, double* H_out);
+int lrn_schur_get(lrn_ctx* ctx, double* H_out);
+/* BBBB + eps*I (predictor_corrector.jl:74) */
+int lrn_schur_add_diag(lrn_ctx* ctx, double eps);
+/* cholesky(BBBB) (predictor_corrector.jl:57); info > 0: not PD at that column */
+int lrn_schur_factor(lrn_ctx* ctx, int* info);
+/* dely = L' \ (L \ h) (predictor_corrector.jl:90,199) */
+int lrn_schur_solve(lrn_ctx* ctx, const double* h, double* dely);
+/* multi-GPU exchange: pack the owned column blocks / unpack the all-gathered buffer */
+int64_t lrn_schur_shard_doubles(lrn_ctx* ctx);
+int lrn_schur_export_shard(lrn_ctx* ctx, double* buf);
+int lrn_schur_import_all(lrn_ctx* ctx, const double* buf_all);
+
+/* ---- right-hand sides: makeRHS (src/makeBBBB.jl:221-228), corrector :186 --------------- */
+/* h = Rp + sum AA*vec(W (Rd+S) W) ; Rd_plus_S: msz x msz per block, concatenated */
+int lrn_make_rhs(lrn_ctx* ctx, const double* Rp, const double* const* RdS, double* h);
+
+/* ---- CG operator and preconditioners (src/Solvers.jl:572-904) ------------------------- */
+/* Ax = sum AA vec(W mat(AA'x) W) + C_lin((X_lin.*S_lin_inv).*(C_lin'x))   (MyA, :582-614) */
+int lrn_matvec(lrn_ctx* ctx, const double* x, double* Ax);
+/* prec: 0 none (MyM_no), 1 H_alpha (Prec_for_CG_tilS_prep :674-809), 2 H_beta
+ * (Prec_for_CG_beta :624-663).  info > 0: a Cholesky inside the setup failed. */
+int lrn_prec_setup(lrn_ctx* ctx, int prec, int erank, int aamat, int* info);
+/* Mx = M^{-1} x (MyM :866-904, MyM_beta :670-672, MyM_no :620-622) */
+int lrn_prec_apply(lrn_ctx* ctx, const double* x, double* Mx);
+/* cg(A, h; tol, maxIter, precon) of ConjugateGradients.jl 0.1 (call sites
+ * predictor_corrector.jl:134,235), device-resident. */
+int lrn_pcg(lrn_ctx* ctx, const double* h, double tol, int maxit, double* x, int* exit_code,
+            int* iters);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+/* milliseconds of the named phase in the last call that ran it, measured with HIP events
+ * on the context's stream ("gemm1","gemm2","gemm3","sparse","assemble","factor","solve",...);
+ * returns LRN_ERR_ARG for an unknown key. */
+int lrn_get_timing(lrn_ctx* ctx, const char* key, double* ms);
+int64_t lrn_get_count(lrn_ctx* ctx, const char* key);
+/* FP64 MFMA issue-rate probe (TFLOP/s of a register-only v_mfma_f64_16x16x4_f64 loop) */
+int lrn_mfma_f64_peak(lrn_ctx* ctx, double* tflops);
+/* streaming-copy probe: achieved HBM GB/s of a 16 B/lane device copy of `bytes` */
+int lrn_hbm_copy_peak(lrn_ctx* ctx, int64_t bytes, double* gbps);
+
+/* ---- building blocks exposed for unit tests (tests/ only) ------------------------------ */
+int lrn_dbg_gemm(lrn_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha,
+                 const double* A, int lda, const double* B, int ldb, double beta, double* C,
+                 int ldc, int flags, int ksplit);
+int lrn_dbg_mfma_probe(lrn_ctx* ctx, const double* A16x4, const double* B4x16, double* D16x16);
+int lrn_dbg_potrf(lrn_ctx* ctx, int n, double* A, int* info);
+int lrn_dbg_potrs(lrn_ctx* ctx, int n, const double* A, const double* b, double* x, int* info);
+int lrn_dbg_trsm(lrn_ctx* ctx, int n, int nrhs, int trans, const double* A, double* B, int* info);
+int lrn_dbg_svd_jacobi(lrn_ctx* ctx, int n, const double* A, double* U_sigma, double* V,
+                       double* sigma, int* sweeps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORAINE_HIP_H */

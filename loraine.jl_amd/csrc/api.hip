@@ -1,0 +1,376 @@
+// extern "C" entry points of libloraine_hip.so (see include/loraine_hip.h).
+#include <cstring>
+
+#include "../../include/loraine_hip.h"
+#include "ctx.h"
+
+using namespace lrn;
+
+void lrn_free_model(lrn_ctx* c);
+extern double lrn_opt_dense_threshold;
+namespace lrn {
+void set_batch_opts(long t, long p);
+void prec_free(lrn_ctx* c);
+}
+
+extern "C" {
+
+int lrn_version(void) { return 100; }
+
+int lrn_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int lrn_create(lrn_ctx** out, int device) {
+  if (!out) return LRN_ERR_ARG;
+  *out = nullptr;
+  int n = lrn_device_count();
+  if (n <= 0 || device < 0 || device >= n) return LRN_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return LRN_ERR_HIP;
+  lrn_ctx* c = new lrn_ctx();
+  c->device = device;
+  c->profile = false;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return LRN_ERR_HIP;
+  }
+  *out = c;
+  return LRN_OK;
+}
+
+int lrn_destroy(lrn_ctx* c) {
+  if (!c) return LRN_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  prec_free(c);
+  lrn_free_model(c);
+  release(c->info_dev);
+  release(c->scratch);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return LRN_OK;
+}
+
+const char* lrn_last_error(lrn_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int lrn_set_option(lrn_ctx* c, const char* key, double value) {
+  if (!c || !key) return LRN_ERR_ARG;
+  if (!strcmp(key, "dense_threshold")) lrn_opt_dense_threshold = value;
+  else if (!strcmp(key, "profile")) c->profile = value != 0.0;
+  else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); c->T_cap = c->P_cap = 0; }
+  else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
+  else if (!strcmp(key, "shard_bs")) { if (value < 1) return LRN_ERR_ARG; c->shard_bs = (int)value; }
+  else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }
+  else return set_error(c, LRN_ERR_ARG, "unknown option %s", key);
+  return LRN_OK;
+}
+
+int lrn_set_shard(lrn_ctx* c, int rank, int world) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return LRN_ERR_ARG;
+  if (world > 1 && !(c->nlmi == 1)) return set_error(c, LRN_ERR_STATE, "column sharding needs nlmi == 1");
+  c->rank = rank;
+  c->world = world;
+  return LRN_OK;
+}
+
+int lrn_set_scaling(lrn_ctx* c, int il, const double* W, const double* G) {
+  if (!c || il < 0 || il >= c->nlmi || !W) return LRN_ERR_ARG;
+  LmiBlock& b = c->lmi[il];
+  size_t mm = (size_t)b.msz * b.msz * 8;
+  LRN_TRY(copy_in(c, b.W.p, W, mm));
+  b.have_W = true;
+  if (G) {
+    LRN_TRY(copy_in(c, b.G.p, G, mm));
+    b.have_G = true;
+  }
+  return LRN_OK;
+}
+
+int lrn_set_lin(lrn_ctx* c, const double* X_lin, const double* S_lin_inv) {
+  if (!c) return LRN_ERR_ARG;
+  if (c->nlin == 0) return LRN_OK;
+  if (!X_lin || !S_lin_inv) return LRN_ERR_ARG;
+  // tiny vector: form the product on the host side of the boundary
+  std::vector<double> x(c->nlin), s(c->nlin);
+  if (is_device_ptr(X_lin)) {
+    LRN_HIP(c, hipMemcpy(x.data(), X_lin, (size_t)c->nlin * 8, hipMemcpyDeviceToHost));
+    LRN_HIP(c, hipMemcpy(s.data(), S_lin_inv, (size_t)c->nlin * 8, hipMemcpyDeviceToHost));
+  } else {
+    memcpy(x.data(), X_lin, (size_t)c->nlin * 8);
+    memcpy(s.data(), S_lin_inv, (size_t)c->nlin * 8);
+  }
+  for (int i = 0; i < c->nlin; ++i) x[i] *= s[i];
+  return copy_in(c, c->lin_xs.p, x.data(), (size_t)c->nlin * 8);
+}
+
+int lrn_schur_assemble(lrn_ctx* c, int mode, double* H_out) {
+  if (!c) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  LRN_TRY(schur_assemble(c, mode));
+  if (H_out) return schur_get(c, H_out);
+  return LRN_OK;
+}
+
+int lrn_schur_get(lrn_ctx* c, double* H_out) {
+  if (!c || !H_out) return LRN_ERR_ARG;
+  return schur_get(c, H_out);
+}
+
+int lrn_schur_add_diag(lrn_ctx* c, double eps) { return c ? schur_add_diag(c, eps) : LRN_ERR_ARG; }
+
+int lrn_schur_factor(lrn_ctx* c, int* info) {
+  if (!c) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  return schur_factor(c, info);
+}
+
+int lrn_schur_solve(lrn_ctx* c, const double* h, double* dely) {
+  if (!c || !h || !dely) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  return schur_solve(c, h, dely);
+}
+
+// ---- multi-GPU exchange buffers: block-cyclic column blocks, rank-major
+static int shard_geom(lrn_ctx* c, int* nblk, int* bpr) {
+  *nblk = (c->nvar + c->shard_bs - 1) / c->shard_bs;
+  *bpr = (*nblk + c->world - 1) / c->world;
+  return LRN_OK;
+}
+
+int64_t lrn_schur_shard_doubles(lrn_ctx* c) {
+  if (!c || c->nvar <= 0) return 0;
+  int nblk, bpr;
+  shard_geom(c, &nblk, &bpr);
+  return (int64_t)bpr * c->shard_bs * c->nvar;
+}
+
+int lrn_schur_export_shard(lrn_ctx* c, double* buf) {
+  if (!c || !buf) return LRN_ERR_ARG;
+  if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  if (!is_device_ptr(buf)) return set_error(c, LRN_ERR_ARG, "shard buffer must be device memory");
+  int nblk, bpr;
+  shard_geom(c, &nblk, &bpr);
+  const long n = c->nvar, bs = c->shard_bs;
+  for (int lb = 0; lb < bpr; ++lb) {
+    int gb = lb * c->world + c->rank;
+    double* dst = buf + (long)lb * bs * n;
+    if (gb >= nblk) {
+      LRN_HIP(c, hipMemsetAsync(dst, 0, (size_t)bs * n * 8, c->stream));
+      continue;
+    }
+    long c0 = (long)gb * bs, nc = std::min<long>(bs, n - c0);
+    LRN_HIP(c, hipMemcpyAsync(dst, c->H.as<double>() + c0 * n, (size_t)nc * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (nc < bs) LRN_HIP(c, hipMemsetAsync(dst + nc * n, 0, (size_t)(bs - nc) * n * 8, c->stream));
+  }
+  LRN_HIP(c, hipStreamSynchronize(c->stream));
+  return LRN_OK;
+}
+
+int lrn_schur_import_all(lrn_ctx* c, const double* buf_all) {
+  if (!c || !buf_all) return LRN_ERR_ARG;
+  if (!is_device_ptr(buf_all)) return set_error(c, LRN_ERR_ARG, "gathered buffer must be device memory");
+  int nblk, bpr;
+  shard_geom(c, &nblk, &bpr);
+  const long n = c->nvar, bs = c->shard_bs;
+  const long per_rank = (long)bpr * bs * n;
+  for (int r = 0; r < c->world; ++r)
+    for (int lb = 0; lb < bpr; ++lb) {
+      int gb = lb * c->world + r;
+      if (gb >= nblk) continue;
+      long c0 = (long)gb * bs, nc = std::min<long>(bs, n - c0);
+      LRN_HIP(c, hipMemcpyAsync(c->H.as<double>() + c0 * n, buf_all + (long)r * per_rank + (long)lb * bs * n,
+                                (size_t)nc * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+  LRN_HIP(c, hipStreamSynchronize(c->stream));
+  c->have_H = true;
+  c->have_L = false;
+  return LRN_OK;
+}
+
+// ---- measurement
+int lrn_get_timing(lrn_ctx* c, const char* key, double* ms) {
+  if (!c || !key || !ms) return LRN_ERR_ARG;
+  auto it = c->timing.find(key);
+  if (it == c->timing.end()) { *ms = 0.0; return LRN_ERR_ARG; }
+  *ms = it->second;
+  return LRN_OK;
+}
+
+int64_t lrn_get_count(lrn_ctx* c, const char* key) {
+  if (!c || !key) return 0;
+  auto it = c->counts.find(key);
+  return it == c->counts.end() ? 0 : it->second;
+}
+
+int lrn_mfma_f64_peak(lrn_ctx* c, double* tflops) {
+  if (!c || !tflops) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  return mfma_f64_peak(c->stream, tflops);
+}
+
+__global__ void copy16_kernel(const double2* __restrict__ src, double2* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int lrn_hbm_copy_peak(lrn_ctx* c, int64_t bytes, double* gbps) {
+  if (!c || !gbps || bytes < 4096) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf a, b;
+  LRN_TRY(ensure(c, a, (size_t)bytes, true));
+  LRN_TRY(ensure(c, b, (size_t)bytes, true));
+  long n = bytes / 16;
+  hipLaunchKernelGGL(copy16_kernel, dim3(2048), dim3(256), 0, c->stream, a.as<double2>(), b.as<double2>(), n);
+  (void)hipEventRecord(c->ev0, c->stream);
+  const int reps = 5;
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(copy16_kernel, dim3(2048), dim3(256), 0, c->stream, a.as<double2>(), b.as<double2>(), n);
+  (void)hipEventRecord(c->ev1, c->stream);
+  (void)hipEventSynchronize(c->ev1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  *gbps = 2.0 * (double)n * 16.0 * reps / (ms * 1e-3) / 1e9;
+  release(a);
+  release(b);
+  return LRN_OK;
+}
+
+// ---- debug / unit-test building blocks
+int lrn_dbg_gemm(lrn_ctx* c, int transA, int transB, int M, int N, int K, double alpha, const double* A,
+                 int lda, const double* B, int ldb, double beta, double* C, int ldc, int flags, int ksplit) {
+  if (!c || !A || !B || !C) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  // host column-major operands: A is (transA ? K x M : M x K) with leading dim lda, etc.
+  size_t a_el = (size_t)lda * (transA ? M : K), b_el = (size_t)ldb * (transB ? K : N), c_el = (size_t)ldc * N;
+  DBuf dA, dB, dC, dS;
+  LRN_TRY(ensure(c, dA, a_el * 8));
+  LRN_TRY(ensure(c, dB, b_el * 8));
+  LRN_TRY(ensure(c, dC, c_el * 8));
+  LRN_TRY(copy_in(c, dA.p, A, a_el * 8));
+  LRN_TRY(copy_in(c, dB.p, B, b_el * 8));
+  LRN_TRY(copy_in(c, dC.p, C, c_el * 8));
+  GemmDesc g;
+  g.A = dA.as<double>(); g.B = dB.as<double>();
+  g.M = M; g.N = N; g.K = K;
+  if (!transA) { g.sAm = 1; g.sAk = lda; } else { g.sAm = lda; g.sAk = 1; }
+  if (!transB) { g.sBk = 1; g.sBn = ldb; } else { g.sBk = ldb; g.sBn = 1; }
+  g.alpha = alpha; g.flags = flags;
+  int rc;
+  if (ksplit > 1 || (flags & GEMM_KSEG_TRI)) {
+    if (ksplit < 1) ksplit = 1;
+    LRN_TRY(ensure(c, dS, (size_t)ksplit * M * N * 8, true));
+    g.C = dS.as<double>(); g.sCm = 1; g.sCn = M; g.ksplit = ksplit; g.sCs = (long)M * N; g.beta = 0.0;
+    if (flags & GEMM_KSEG_TRI) {
+      // test convention: K = ld*ld with ld = isqrt(K)
+      int ld = 1;
+      while ((long)(ld + 1) * (ld + 1) <= K) ++ld;
+      g.kseg_ld = ld; g.kseg_cols = ld;
+    }
+    rc = gemm(c->stream, g);
+    if (rc == LRN_OK) {
+      // compact reduce then C = beta*C + sum
+      DBuf dR;
+      LRN_TRY(ensure(c, dR, (size_t)M * N * 8, true));
+      rc = reduce_slabs(c->stream, dS.as<double>(), (long)M * N, ksplit, dR.as<double>(), (long)M * N, 0.0);
+      std::vector<double> r((size_t)M * N), cc(c_el);
+      LRN_TRY(copy_out(c, r.data(), dR.p, (size_t)M * N * 8));
+      LRN_TRY(copy_out(c, cc.data(), dC.p, c_el * 8));
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < M; ++i) cc[(size_t)i + (size_t)j * ldc] = beta * cc[(size_t)i + (size_t)j * ldc] + r[(size_t)i + (size_t)j * M];
+      LRN_TRY(copy_in(c, dC.p, cc.data(), c_el * 8));
+      release(dR);
+    }
+  } else {
+    g.C = dC.as<double>(); g.sCm = 1; g.sCn = ldc; g.beta = beta;
+    rc = gemm(c->stream, g);
+  }
+  if (rc != LRN_OK) return set_error(c, rc, "gemm launch failed");
+  rc = copy_out(c, C, dC.p, c_el * 8);
+  release(dA); release(dB); release(dC); release(dS);
+  return rc;
+}
+
+int lrn_dbg_mfma_probe(lrn_ctx* c, const double* A, const double* B, double* D) {
+  if (!c || !A || !B || !D) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf dA, dB, dD;
+  LRN_TRY(ensure(c, dA, 64 * 8));
+  LRN_TRY(ensure(c, dB, 64 * 8));
+  LRN_TRY(ensure(c, dD, 256 * 8, true));
+  LRN_TRY(copy_in(c, dA.p, A, 64 * 8));
+  LRN_TRY(copy_in(c, dB.p, B, 64 * 8));
+  LRN_TRY(mfma_f64_probe(c->stream, dA.as<double>(), dB.as<double>(), dD.as<double>()));
+  int rc = copy_out(c, D, dD.p, 256 * 8);
+  release(dA); release(dB); release(dD);
+  return rc;
+}
+
+static int dbg_factor(lrn_ctx* c, int n, const double* A, DBuf& dA, DBuf& dI, int* info) {
+  DBuf dW;
+  LRN_TRY(ensure(c, dA, (size_t)n * n * 8));
+  LRN_TRY(ensure(c, dI, chol_linv_doubles(n) * 8));
+  LRN_TRY(ensure(c, dW, (size_t)n * CHOL_NB * 8));
+  LRN_TRY(ensure(c, c->info_dev, 64));
+  LRN_TRY(copy_in(c, dA.p, A, (size_t)n * n * 8));
+  LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, c->stream));
+  LRN_TRY(potrf_lower(c->stream, dA.as<double>(), n, n, dI.as<double>(), dW.as<double>(), c->info_dev.as<int>()));
+  int h = 0;
+  LRN_TRY(copy_out(c, &h, c->info_dev.p, 4));
+  if (info) *info = h;
+  release(dW);
+  return LRN_OK;
+}
+
+int lrn_dbg_potrf(lrn_ctx* c, int n, double* A, int* info) {
+  if (!c || !A || n <= 0) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf dA, dI;
+  LRN_TRY(dbg_factor(c, n, A, dA, dI, info));
+  int rc = copy_out(c, A, dA.p, (size_t)n * n * 8);
+  release(dA); release(dI);
+  return rc;
+}
+
+int lrn_dbg_potrs(lrn_ctx* c, int n, const double* A, const double* b, double* x, int* info) {
+  if (!c || !A || !b || !x || n <= 0) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf dA, dI, v;
+  int inf = 0;
+  LRN_TRY(dbg_factor(c, n, A, dA, dI, &inf));
+  if (info) *info = inf;
+  if (inf != 0) { release(dA); release(dI); return LRN_OK; }
+  LRN_TRY(ensure(c, v, (size_t)(4 * n + 64) * 8, true));
+  double* vb = v.as<double>();
+  LRN_TRY(copy_in(c, vb, b, (size_t)n * 8));
+  LRN_TRY(potrs_vec(c->stream, dA.as<double>(), n, n, dI.as<double>(), vb, vb + n, vb + 2 * n, vb + 3 * n));
+  int rc = copy_out(c, x, vb + n, (size_t)n * 8);
+  release(dA); release(dI); release(v);
+  return rc;
+}
+
+int lrn_dbg_trsm(lrn_ctx* c, int n, int nrhs, int trans, const double* A, double* B, int* info) {
+  if (!c || !A || !B || n <= 0 || nrhs <= 0) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf dA, dI, dB, dT;
+  int inf = 0;
+  LRN_TRY(dbg_factor(c, n, A, dA, dI, &inf));
+  if (info) *info = inf;
+  if (inf != 0) { release(dA); release(dI); return LRN_OK; }
+  LRN_TRY(ensure(c, dB, (size_t)n * nrhs * 8));
+  LRN_TRY(ensure(c, dT, (size_t)CHOL_NB * nrhs * 8));
+  LRN_TRY(copy_in(c, dB.p, B, (size_t)n * nrhs * 8));
+  LRN_TRY(trsm_left_lower(c->stream, dA.as<double>(), n, n, dI.as<double>(), trans != 0, dB.as<double>(), nrhs, n,
+                          dT.as<double>()));
+  int rc = copy_out(c, B, dB.p, (size_t)n * nrhs * 8);
+  release(dA); release(dI); release(dB); release(dT);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// Library context: device-resident model data, NT scaling, Schur matrix, solver state.
+#pragma once
+#include <map>
+
+#include "chol.h"
+#include "lrn_common.h"
+
+struct LmiBlock {
+  int msz = 0;
+  long nent = 0;            // total stored entries (sparse lists)
+  // --- constraint data in sigma-POSITION order (position p <-> constraint sigma[p])
+  std::vector<int> sigma;   // position -> constraint (0-based)
+  std::vector<int> ipos;    // constraint -> position
+  std::vector<long> nnz;    // per position
+  int qA = 0;               // reference dense/sparse split (positions < qA are "branch 1")
+  int nd = 0;               // positions [0,nd): T_i = W A_i W by MFMA GEMM, A stored dense
+  int q_wave = 0;           // positions [nd,q_wave): wave-per-pair kernel; [q_wave,n): thread-per-pair
+  int npos_nz = 0;          // positions with nnz > 0 form the prefix [0,npos_nz)
+  lrn::DBuf ent_ptr;        // int64 [nvar+1]
+  lrn::DBuf ent_r, ent_c;   // int32 [nent]
+  lrn::DBuf ent_v;          // double [nent]   value of A_j (= -AA)
+  lrn::DBuf Adense;         // double [nd * msz^2], slot s = position s
+  lrn::DBuf hidx;           // int32 [nvar] position -> row/col index of the Schur matrix
+  lrn::DBuf sigma_d, ipos_d; // int32 [nvar] device copies of sigma / ipos
+  // rank-one factors (datarank = -1): CSR by constraint (natural order)
+  bool has_B = false;
+  long bnnz = 0;
+  lrn::DBuf b_ptr, b_col, b_val;
+  // --- NT scaling state (device, msz x msz col-major)
+  lrn::DBuf X, S, W, G, Gi, Si, D, DDsi;
+  bool have_W = false, have_G = false;
+};
+
+struct lrn_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int nlmi = 0, nvar = 0, nlin = 0;
+  std::vector<LmiBlock> lmi;
+  bool pos_space = false;       // Schur matrix kept in sigma-position space (nlmi == 1)
+  // linear block C_lin (nvar x nlin) stored by linear constraint (CSC)
+  lrn::DBuf cl_ptr, cl_row, cl_val;   // int64 [nlin+1], int32, double
+  lrn::DBuf lin_xs;                   // X_lin .* S_lin_inv  [nlin]
+  // Schur complement
+  lrn::DBuf H;          // assembled (lower triangle authoritative), nvar x nvar
+  lrn::DBuf L;          // factor
+  lrn::DBuf Linv;       // inverse diagonal blocks
+  lrn::DBuf cholwork;   // nvar * NB
+  lrn::DBuf info_dev;   // int
+  lrn::DBuf v0, v1, v2, v3;   // nvar-vectors (solve scratch)
+  bool have_H = false, have_L = false;
+  // assembly workspaces
+  lrn::DBuf P, T, slabs, Hd, BG;
+  long P_cap = 0, T_cap = 0;   // capacity in matrices
+  // shard (multi-GPU): this rank assembles owner columns with (pos / shard_bs) % world == rank
+  int rank = 0, world = 1, shard_bs = 128;
+  // timing of the last assembly / factor / solve (ms, HIP events on ctx stream)
+  std::map<std::string, double> timing;
+  std::map<std::string, long> counts;
+  bool profile = true;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // generic scratch
+  lrn::DBuf scratch;
+  // preconditioner / CG state
+  struct Prec* prec = nullptr;
+};
+
+namespace lrn {
+int set_error(lrn_ctx* c, int code, const char* fmt, ...);
+int ensure(lrn_ctx* c, DBuf& b, size_t bytes, bool zero = false);
+void release(DBuf& b);
+bool is_device_ptr(const void* p);
+int copy_in(lrn_ctx* c, void* dst_dev, const void* src, size_t bytes);    // src host or device
+int copy_out(lrn_ctx* c, void* dst, const void* src_dev, size_t bytes);   // dst host or device
+void tic(lrn_ctx* c);
+void toc(lrn_ctx* c, const char* key);
+
+// schur.hip
+int schur_assemble(lrn_ctx* c, int mode);
+int schur_factor(lrn_ctx* c, int* info);
+int schur_solve(lrn_ctx* c, const double* h, double* dely);
+int schur_add_diag(lrn_ctx* c, double eps);
+int schur_get(lrn_ctx* c, double* Hout);
+int schur_matvec_dense(lrn_ctx* c, const double* x_dev, double* y_dev);
+}  // namespace lrn
+
+#define LRN_HIP(c, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess)                                                                 \
+      return lrn::set_error((c), LRN_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                   \
+  } while (0)
+#define LRN_TRY(expr)             \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != LRN_OK) return rc__; \
+  } while (0)

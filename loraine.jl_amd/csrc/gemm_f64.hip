@@ -1,0 +1,395 @@
+// FP64 MFMA GEMM for gfx950 (MI355X): the contraction engine behind the Schur assembly
+// (W*A_k*W products, <A_i, T_j> inner products), the blocked Cholesky trailing update,
+// NT-scaling products and the CG mat-vec.
+//
+// Design (CDNA4-first, see DESIGN.md "K1"):
+//  * v_mfma_f64_16x16x4_f64: one wave owns a (BM/2)x(BN/2) sub-tile = (BM/32)x(BN/32) MFMA
+//    tiles, 4 waves (2x2) per 256-thread workgroup; all accumulators independent, so the
+//    matrix pipe is issue-bound.  f64 C/D lane map: col = lane&15, row = (lane>>4) + 4*reg.
+//  * operands staged global -> registers -> LDS, double-buffered, one barrier per K-tile;
+//    the next tile's global loads are in flight under the current tile's MFMAs.
+//  * LDS images padded so that the ds_read_b64 fragment reads are bank-conflict free:
+//    [k][m] images use row stride BM+16 (== 16 mod 32), [m][k] images use stride BK+2.
+//  * every operand is addressed by element strides, so all transposes / leading dimensions /
+//    batches share this kernel; the launcher orients the problem so that the lane-contiguous
+//    MFMA output dimension is the memory-contiguous dimension of C.
+//  * blockIdx -> tile map is XCD-aware (8 XCDs, private L2s): each XCD walks a contiguous
+//    range of tiles that share an operand panel.
+//  * split-K writes per-split slabs that a second kernel reduces in fixed order
+//    (deterministic; no float atomics).
+#include "lrn_common.h"
+
+#include <map>
+#include <utility>
+#include <vector>
+
+namespace lrn {
+
+static constexpr int BK = 16;
+static constexpr int MAX_KSPLIT = 64;
+
+struct GemmParams {
+  GemmDesc d;
+  int tilesM, tilesN;
+  int kchunk;                    // K elements per split (multiple of BK), non-KSEG
+  int kcols[MAX_KSPLIT + 1];     // KSEG: column range per split
+  const int2* tile_list;         // (tm, tn) per workgroup, super-tile order
+};
+
+#define MFMA_F64_ROW(lane, r) (((lane) >> 4) + 4 * (r))
+
+template <int BM, bool KC>
+__device__ __forceinline__ int lds_idx(int m, int k) {
+  // KC: k-contiguous image [m][k], stride BK+2 ; else [k][m], stride BM+16
+  return KC ? (m * (BK + 2) + k) : (k * (BM + 16) + m);
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool KSEG>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
+  constexpr int TM = BM / 32, TN = BN / 32;       // MFMA tiles per wave
+  constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+  constexpr int LA = BK * (BM + 16), LB = BK * (BN + 16);
+  __shared__ double lds[2 * (LA + LB)];
+
+  const GemmDesc& d = p.d;
+  // ---- tile decode (XCD-aware, bijective for any grid size)
+  int tm, tn;
+  {
+    int bid = blockIdx.x, nwg = gridDim.x;
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int2 tt = p.tile_list[swz];
+    tm = tt.x;
+    tn = tt.y;
+  }
+  const int ks = blockIdx.z % d.ksplit;
+  const int bz = blockIdx.z / d.ksplit;
+  const double* __restrict__ Ag = d.A + (long)bz * d.bA;
+  const double* __restrict__ Bg = d.B + (long)bz * d.bB;
+  double* __restrict__ Cg = d.C + (long)bz * d.bC + (long)ks * d.sCs;
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- K range
+  long kcur, kend;             // non-KSEG
+  int segc = 0, segcend = 0, segr = 0;   // KSEG
+  if (KSEG) {
+    segc = p.kcols[ks];
+    segcend = p.kcols[ks + 1];
+    segr = (segc / 128) * 128;
+    kcur = 0; kend = 0;
+  } else {
+    kcur = (long)ks * p.kchunk;
+    kend = kcur + p.kchunk;
+    if (kend > d.K) kend = d.K;
+  }
+
+  // ---- per-thread staging geometry
+  // A: !AKC -> m fastest over threads ; AKC -> k fastest
+  int a_m, a_k, a_dm, a_dk;    // first element (tile-local) and per-i increments
+  if (AKC) { a_k = t & 15; a_m = t >> 4; a_dm = 16; a_dk = 0; }
+  else     { a_m = t % BM; a_k = t / BM; a_dm = 0; a_dk = 256 / BM; }
+  int b_n, b_k, b_dn, b_dk;
+  if (BKC) { b_k = t & 15; b_n = t >> 4; b_dn = 16; b_dk = 0; }
+  else     { b_n = t % BN; b_k = t / BN; b_dn = 0; b_dk = 256 / BN; }
+  const double* pa = Ag + (long)(m0 + a_m) * d.sAm + (long)a_k * d.sAk;
+  const double* pb = Bg + (long)(n0 + b_n) * d.sBn + (long)b_k * d.sBk;
+  const long a_step = (long)a_dm * d.sAm + (long)a_dk * d.sAk;
+  const long b_step = (long)b_dn * d.sBn + (long)b_dk * d.sBk;
+
+  double ra[EA], rb[EB];
+  v4f64 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+  auto chunk_valid = [&]() -> bool { return KSEG ? (segc < segcend) : (kcur < kend); };
+  auto chunk_base = [&]() -> long { return KSEG ? ((long)segc * d.kseg_ld + segr) : kcur; };
+  auto chunk_len = [&]() -> int {
+    long rem = KSEG ? (long)(d.kseg_ld - segr) : (kend - kcur);
+    return rem < BK ? (int)rem : BK;
+  };
+  auto chunk_next = [&]() {
+    if (KSEG) {
+      segr += BK;
+      if (segr >= d.kseg_ld) { ++segc; segr = (segc / 128) * 128; }
+    } else {
+      kcur += BK;
+    }
+  };
+  auto gload = [&](long kb, int len) {
+    const double* qa = pa + kb * d.sAk;
+#pragma unroll
+    for (int i = 0; i < EA; ++i) {
+      bool ok = (m0 + a_m + i * a_dm < d.M) && (a_k + i * a_dk < len);
+      ra[i] = ok ? qa[i * a_step] : 0.0;
+    }
+    const double* qb = pb + kb * d.sBk;
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
+      bool ok = (n0 + b_n + i * b_dn < d.N) && (b_k + i * b_dk < len);
+      rb[i] = ok ? qb[i * b_step] : 0.0;
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* sa = lds + buf * (LA + LB);
+    double* sb = sa + LA;
+#pragma unroll
+    for (int i = 0; i < EA; ++i) sa[lds_idx<BM, AKC>(a_m + i * a_dm, a_k + i * a_dk)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < EB; ++i) sb[lds_idx<BN, BKC>(b_n + i * b_dn, b_k + i * b_dk)] = rb[i];
+  };
+
+  if (chunk_valid()) {
+    gload(chunk_base(), chunk_len());
+    chunk_next();
+    lstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  const int fr = lane & 15, fk = lane >> 4;
+  bool more = true;
+  // number of chunks is uniform across the workgroup (depends only on block indices)
+  {
+    // first chunk may not exist at all (empty split): then nothing to do
+    bool any = KSEG ? (p.kcols[ks] < p.kcols[ks + 1]) : ((long)ks * p.kchunk < d.K);
+    more = any;
+  }
+  while (more) {
+    bool have_next = chunk_valid();
+    if (have_next) {
+      gload(chunk_base(), chunk_len());
+      chunk_next();
+    }
+    const double* sa = lds + cur * (LA + LB);
+    const double* sb = sa + LA;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = sa[lds_idx<BM, AKC>(wm * (BM / 2) + i * 16 + fr, kk * 4 + fk)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = sb[lds_idx<BN, BKC>(wn * (BN / 2) + j * 16 + fr, kk * 4 + fk)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (have_next) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+    more = have_next;
+  }
+
+  // ---- epilogue
+  const bool x2 = (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
+  const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
+  const bool sq = d.flags & GEMM_SQUARE;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm * (BM / 2) + i * 16 + MFMA_F64_ROW(lane, r);
+        int n = n0 + wn * (BN / 2) + j * 16 + fr;
+        if (m < d.M && n < d.N) {
+          double v = alpha * acc[i][j][r];
+          if (sq) v = v * v;
+          double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
+          if (d.beta != 0.0) v += d.beta * (*c);
+          *c = v;
+        }
+      }
+}
+
+template <int BM, int BN, bool KSEG>
+static void launch4(hipStream_t st, const GemmParams& p, bool akc, bool bkc, dim3 grid) {
+  if (akc && bkc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, KSEG>), grid, dim3(256), 0, st, p);
+  else if (akc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, KSEG>), grid, dim3(256), 0, st, p);
+  else if (bkc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, KSEG>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, KSEG>), grid, dim3(256), 0, st, p);
+}
+
+// (tm, tn) enumeration: 8x8 super-tiles (tm fastest inside), only the tiles a TRI flag keeps.
+// Consecutive list entries share operand panels, and the XCD swizzle hands each XCD a
+// contiguous run of the list, so co-resident workgroups of one L2 re-use panels.
+static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count) {
+  struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
+  struct Val { int2* dev; int n; };
+  static std::map<Key, Val> cache[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto& cm = cache[dev & 15];
+  Key k{tilesM, tilesN, tri};
+  auto it = cm.find(k);
+  if (it != cm.end()) { *count = it->second.n; return it->second.dev; }
+  std::vector<int2> v;
+  const int GS = 8;
+  for (int sn = 0; sn < tilesN; sn += GS)
+    for (int sm = 0; sm < tilesM; sm += GS)
+      for (int tn = sn; tn < sn + GS && tn < tilesN; ++tn)
+        for (int tm = sm; tm < sm + GS && tm < tilesM; ++tm) {
+          if (tri == GEMM_TRI_LOWER && tn > tm) continue;
+          if (tri == GEMM_TRI_UPPER && tm > tn) continue;
+          v.push_back(make_int2(tm, tn));
+        }
+  Val val{nullptr, (int)v.size()};
+  if (hipMalloc(&val.dev, sizeof(int2) * (v.size() + 1)) != hipSuccess) { *count = 0; return nullptr; }
+  (void)hipMemcpy(val.dev, v.data(), sizeof(int2) * v.size(), hipMemcpyHostToDevice);
+  cm[k] = val;
+  *count = val.n;
+  return val.dev;
+}
+
+int gemm(hipStream_t st, const GemmDesc& din) {
+  GemmParams p;
+  p.d = din;
+  GemmDesc& d = p.d;
+  if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return LRN_OK;
+  if (d.ksplit < 1) d.ksplit = 1;
+  if (d.ksplit > MAX_KSPLIT) return LRN_ERR_ARG;
+  // Orient so that the kernel's n (lane-contiguous in the MFMA result) is the contiguous
+  // dimension of C: C^T = B^T A^T.
+  long asCm = d.sCm < 0 ? -d.sCm : d.sCm, asCn = d.sCn < 0 ? -d.sCn : d.sCn;
+  if (asCm < asCn) {
+    std::swap(d.A, d.B);
+    std::swap(d.bA, d.bB);
+    long sAm = d.sBn, sAk = d.sBk, sBk = d.sAk, sBn = d.sAm;
+    d.sAm = sAm; d.sAk = sAk; d.sBk = sBk; d.sBn = sBn;
+    std::swap(d.sCm, d.sCn);
+    std::swap(d.M, d.N);
+    if (d.flags & GEMM_TRI_LOWER) d.flags = (d.flags & ~GEMM_TRI_LOWER) | GEMM_TRI_UPPER;
+    else if (d.flags & GEMM_TRI_UPPER) d.flags = (d.flags & ~GEMM_TRI_UPPER) | GEMM_TRI_LOWER;
+  }
+  const bool tri = d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER);
+  const bool kseg = d.flags & GEMM_KSEG_TRI;
+  // tile choice: 128x128 unless the problem is too small to fill the chip with it
+  long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit;
+  bool small = (d.flags & GEMM_SMALL_TILE) || (t128 < 256 && !(d.flags & GEMM_OFFDIAG_X2) && !kseg);
+  const int BMv = small ? 64 : 128;
+  p.tilesM = (d.M + BMv - 1) / BMv;
+  p.tilesN = (d.N + BMv - 1) / BMv;
+  if (kseg) {
+    if (d.kseg_ld <= 0 || d.kseg_cols <= 0) return LRN_ERR_ARG;
+    d.K = d.kseg_ld * d.kseg_cols;
+    // balance splits by segment length sum
+    double total = 0;
+    for (int c = 0; c < d.kseg_cols; ++c) total += d.kseg_ld - (c / 128) * 128;
+    double accw = 0;
+    int s = 1;
+    p.kcols[0] = 0;
+    for (int c = 0; c < d.kseg_cols && s < d.ksplit; ++c) {
+      accw += d.kseg_ld - (c / 128) * 128;
+      if (accw >= total * s / d.ksplit) p.kcols[s++] = c + 1;
+    }
+    for (; s <= d.ksplit; ++s) p.kcols[s] = d.kseg_cols;
+    p.kchunk = 0;
+  } else {
+    long per = (d.K + d.ksplit - 1) / d.ksplit;
+    per = ((per + BK - 1) / BK) * BK;
+    if (per < BK) per = BK;
+    p.kchunk = (int)per;
+  }
+  int ntile = 0;
+  p.tile_list = get_tile_list(p.tilesM, p.tilesN, d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER), &ntile);
+  if (!p.tile_list || ntile <= 0) return LRN_ERR_NOMEM;
+  (void)tri;
+  const bool akc = (d.sAk == 1 && d.sAm != 1);
+  const bool bkc = (d.sBk == 1 && d.sBn != 1);
+  dim3 grid(ntile, 1, d.batch * d.ksplit);
+  if (grid.z > 65535) return LRN_ERR_ARG;
+  if (small) {
+    if (kseg) launch4<64, 64, true>(st, p, akc, bkc, grid);
+    else launch4<64, 64, false>(st, p, akc, bkc, grid);
+  } else {
+    if (kseg) launch4<128, 128, true>(st, p, akc, bkc, grid);
+    else launch4<128, 128, false>(st, p, akc, bkc, grid);
+  }
+  return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+}
+
+// ------------------------------------------------------------------ slab reduction
+__global__ void reduce_slabs_kernel(const double* __restrict__ slabs, long stride, int nslab,
+                                    double* __restrict__ out, long n, double beta) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long step = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += slabs[(long)k * stride + i];
+    out[i] = (beta != 0.0 ? beta * out[i] : 0.0) + s;
+  }
+}
+
+int reduce_slabs(hipStream_t st, const double* slabs, long stride, int nslab, double* out,
+                 long n, double beta) {
+  if (n <= 0) return LRN_OK;
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slabs, stride,
+                     nslab, out, n, beta);
+  return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+}
+
+// ------------------------------------------------------------------ MFMA probes
+__global__ void mfma_probe_kernel(const double* A, const double* B, double* D) {
+  int lane = threadIdx.x;
+  double a = A[(lane & 15) * 4 + (lane >> 4)];   // A[row][k], row-major 16x4
+  double b = B[(lane >> 4) * 16 + (lane & 15)];  // B[k][col], row-major 4x16
+  v4f64 c = {0, 0, 0, 0};
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) D[MFMA_F64_ROW(lane, r) * 16 + (lane & 15)] = c[r];
+}
+
+int mfma_f64_probe(hipStream_t st, const double* A, const double* B, double* D) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, st, A, B, D);
+  return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+}
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+  v4f64 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
+    c5 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c5, 0, 0, 0);
+    c6 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c6, 0, 0, 0);
+    c7 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c7, 0, 0, 0);
+  }
+  v4f64 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+  if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];
+}
+
+int mfma_f64_peak(hipStream_t st, double* tflops) {
+  double* dummy = nullptr;
+  if (hipMalloc(&dummy, 8) != hipSuccess) return LRN_ERR_NOMEM;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int iters = 4000;
+  const int blocks = 256 * 2;       // 2 workgroups of 4 waves per CU -> 2 waves per SIMD
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dummy, 100);
+  hipEventRecord(e0, st);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dummy, iters);
+  hipEventRecord(e1, st);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  double flops = (double)blocks * 4 /*waves*/ * iters * 8 * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipFree(dummy);
+  return LRN_OK;
+}
+
+}  // namespace lrn

@@ -1,0 +1,70 @@
+// Internal declarations shared by the HIP translation units of libloraine_hip.so.
+// gfx950 (MI355X / CDNA4) only.  Public C ABI: include/loraine_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define LRN_OK 0
+#define LRN_ERR_ARG (-1)
+#define LRN_ERR_HIP (-2)
+#define LRN_ERR_STATE (-3)
+#define LRN_ERR_NOMEM (-4)
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+namespace lrn {
+
+// ---------------------------------------------------------------- device buffer
+struct DBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------- GEMM descriptor
+// C[m][n] (+)= alpha * sum_k opA[m][k] * opB[k][n], every operand addressed by strides
+// (in elements), so any transpose / leading dimension / batch layout is one kernel.
+enum : int {
+  GEMM_TRI_LOWER = 1,      // compute only tiles that touch m >= n (needs BM == BN)
+  GEMM_TRI_UPPER = 2,      // compute only tiles that touch m <= n
+  GEMM_OFFDIAG_X2 = 4,     // multiply strictly off-diagonal tiles by 2 (packed-symmetric dot)
+  GEMM_SQUARE = 8,         // epilogue c = (alpha*acc)^2 (+ beta*c)   (rank-one Schur)
+  GEMM_KSEG_TRI = 16,      // K index = (col c, row r) of an ld x ncols matrix; rows
+                           // r < (c / 128) * 128 are skipped (upper tiles of a lower-stored
+                           // symmetric operand)
+  GEMM_SMALL_TILE = 32,    // force the 64x64 tile
+};
+
+struct GemmDesc {
+  const double* A = nullptr;
+  const double* B = nullptr;
+  double* C = nullptr;
+  int M = 0, N = 0, K = 0;
+  long sAm = 0, sAk = 0, sBk = 0, sBn = 0, sCm = 0, sCn = 0;
+  long bA = 0, bB = 0, bC = 0;
+  int batch = 1;
+  double alpha = 1.0, beta = 0.0;
+  int flags = 0;
+  // split-K: C must then point to `ksplit` slabs (slab stride sCs elements); the caller
+  // reduces the slabs (reduce_slabs) -- deterministic, no atomics.
+  int ksplit = 1;
+  long sCs = 0;
+  // GEMM_KSEG_TRI: K = kseg_ld * kseg_cols, segment list derived from (ld, cols)
+  int kseg_ld = 0, kseg_cols = 0;
+};
+
+int gemm(hipStream_t st, const GemmDesc& d);
+// out[i] = beta*out[i] + sum_s slabs[s*stride + i]   (i < n), fixed summation order
+int reduce_slabs(hipStream_t st, const double* slabs, long stride, int nslab, double* out,
+                 long n, double beta);
+// FP64 MFMA issue-rate probe: returns achieved TFLOP/s of a register-only MFMA loop.
+int mfma_f64_peak(hipStream_t st, double* tflops);
+// debug: one 16x16x4 MFMA with explicit operands (checks the lane maps)
+int mfma_f64_probe(hipStream_t st, const double* A16x4, const double* B4x16, double* D16x16);
+
+}  // namespace lrn

@@ -1,0 +1,488 @@
+// Schur-complement assembly  H_ij = tr(A_i W A_j W)  (+ C_lin diag(X_lin/S_lin) C_lin'),
+// factorisation and solve.  Replaces makeBBBBs / makeBBBBsi / _dot / makeBBBB_rank1
+// (reference src/makeBBBB.jl:1-218) and predictor_corrector.jl:36-39,53-90,199.
+//
+// Every unordered pair {i,j} is computed once, by the constraint that comes first in the
+// reference's nnz-sorted order sigmaA (its "owner"), exactly as makeBBBBsi walks it
+// (makeBBBB.jl:77,151,192).  The matrix is kept in sigma-POSITION space when nlmi == 1 so
+// that an owner's results form one contiguous column of the lower triangle -- this is what
+// makes the multi-GPU exchange an all-gather of column blocks.
+//
+//   owner dense  (positions < nd):   T_i = W A_i W on the FP64 MFMA GEMM
+//        GEMM1  P_i = A_i W                      (batched, 2 msz^3)
+//        GEMM2  T_i = W P_i, lower 128-tiles only, strictly-lower tiles scaled by 2 (msz^3)
+//        GEMM3  H[j,i] = <A_j, T_i> for dense j >= i: one TN GEMM whose K loop skips the
+//               upper tiles (packed-symmetric inner product, nvar^2 msz^2 / 2), split-K slabs
+//        gather H[j,i] = sum_e a_e T_i[r_e,c_e] for sparse j
+//   owner sparse (positions >= nd):  one WAVEFRONT per entry (i,j), lanes over the
+//        nnz_i x nnz_j product terms a_e a_f W[c_e,r_f] W[c_f,r_e]   (the _dot kernel);
+//        owners with <= 4 nonzeros use one THREAD per entry (the nnz==1 fast path,
+//        makeBBBB.jl:188-209, is its 1x1 case).
+//   rank-one data (mode -1): BG = B G (sparse x dense), H += (BG BG').^2 with the square
+//        fused in the MFMA GEMM epilogue (makeBBBB.jl:7-14).
+#include <algorithm>
+
+#include "ctx.h"
+
+namespace lrn {
+
+static constexpr int TS = 128;   // packing tile of the lower-stored T
+
+// ------------------------------------------------------------------ sparse pair kernels
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// one wavefront per entry (pi, pj >= pi), pi in [p_lo, p_hi)
+__global__ __launch_bounds__(256) void pair_wave_kernel(
+    const long* __restrict__ ptr, const int* __restrict__ er, const int* __restrict__ ec,
+    const double* __restrict__ ev, const double* __restrict__ W, int msz, int p_lo, int p_hi,
+    int p_end, const int* __restrict__ hidx, double* __restrict__ H, int ldh, int rank, int world,
+    int bs) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int pi = p_lo + blockIdx.y;
+  if (pi >= p_hi) return;
+  if (world > 1 && (pi / bs) % world != rank) return;
+  const int pj = pi + blockIdx.x * 4 + wv;
+  if (pj >= p_end) return;
+  const long ib = ptr[pi], jb = ptr[pj];
+  const int ni = (int)(ptr[pi + 1] - ib), nj = (int)(ptr[pj + 1] - jb);
+  const int total = ni * nj;
+  double acc = 0.0;
+  for (int idx = lane; idx < total; idx += 64) {
+    int e = idx / nj, f = idx - e * nj;
+    int r = er[ib + e], c = ec[ib + e];
+    int p = er[jb + f], q = ec[jb + f];
+    // A_i[r,c] W[c,p] A_j[p,q] W[q,r]
+    acc += ev[ib + e] * ev[jb + f] * W[(long)c + (long)p * msz] * W[(long)q + (long)r * msz];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    int hi = hidx[pi], hj = hidx[pj];
+    int rr = hi > hj ? hi : hj, cc = hi > hj ? hj : hi;
+    H[(long)rr + (long)cc * ldh] += acc;
+  }
+}
+
+// one thread per entry, owners with <= 4 nonzeros
+__global__ __launch_bounds__(256) void pair_thread_kernel(
+    const long* __restrict__ ptr, const int* __restrict__ er, const int* __restrict__ ec,
+    const double* __restrict__ ev, const double* __restrict__ W, int msz, int p_lo, int p_end,
+    const int* __restrict__ hidx, double* __restrict__ H, int ldh, int rank, int world, int bs) {
+  const int pi = p_lo + blockIdx.y;
+  if (pi >= p_end) return;
+  if (world > 1 && (pi / bs) % world != rank) return;
+  const int pj = pi + blockIdx.x * 256 + threadIdx.x;
+  if (pj >= p_end) return;
+  const long ib = ptr[pi], jb = ptr[pj];
+  const int ni = (int)(ptr[pi + 1] - ib), nj = (int)(ptr[pj + 1] - jb);
+  double acc = 0.0;
+  for (int e = 0; e < ni; ++e) {
+    int r = er[ib + e], c = ec[ib + e];
+    double a = ev[ib + e];
+    for (int f = 0; f < nj; ++f) {
+      int p = er[jb + f], q = ec[jb + f];
+      acc += a * ev[jb + f] * W[(long)c + (long)p * msz] * W[(long)q + (long)r * msz];
+    }
+  }
+  int hi = hidx[pi], hj = hidx[pj];
+  int rr = hi > hj ? hi : hj, cc = hi > hj ? hj : hi;
+  H[(long)rr + (long)cc * ldh] += acc;
+}
+
+// dense owner slot s (T stored lower tiles, strictly-lower x2) x sparse other pj
+__global__ __launch_bounds__(256) void dense_sparse_gather_kernel(
+    const long* __restrict__ ptr, const int* __restrict__ er, const int* __restrict__ ec,
+    const double* __restrict__ ev, const double* __restrict__ T, int msz, int s0, int ns, int p_lo,
+    int p_end, const int* __restrict__ hidx, double* __restrict__ H, int ldh) {
+  const int s = blockIdx.y;
+  if (s >= ns) return;
+  const int pj = p_lo + blockIdx.x * 256 + threadIdx.x;
+  if (pj >= p_end) return;
+  const double* Ts = T + (long)s * msz * msz;
+  double acc = 0.0;
+  for (long f = ptr[pj]; f < ptr[pj + 1]; ++f) {
+    int p = er[f], q = ec[f];
+    int tp = p / TS, tq = q / TS;
+    double t;
+    if (tp == tq) t = Ts[(long)p + (long)q * msz];
+    else if (tp > tq) t = 0.5 * Ts[(long)p + (long)q * msz];
+    else t = 0.5 * Ts[(long)q + (long)p * msz];
+    acc += ev[f] * t;
+  }
+  int hi = hidx[s0 + s], hj = hidx[pj];
+  int rr = hi > hj ? hi : hj, cc = hi > hj ? hj : hi;
+  H[(long)rr + (long)cc * ldh] += acc;
+}
+
+// out[(r0+i) + (c0+j)*ldo] += sum_s slab_s[i + j*M]   for computed (lower) tiles
+__global__ void reduce_slabs_tri_kernel(const double* __restrict__ slabs, long stride, int nslab, int M,
+                                        int N, double* __restrict__ out, long ldo) {
+  long total = (long)M * N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % M), j = (int)(e / M);
+    if (i / TS < j / TS) continue;
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += slabs[(long)k * stride + e];
+    out[(long)i + (long)j * ldo] += s;
+  }
+}
+
+// Hd (nd x nd, slot space, lower) scattered into H through hidx (nlmi > 1)
+__global__ void scatter_add_lower_kernel(const double* __restrict__ Hd, int nd, const int* __restrict__ hidx,
+                                         double* __restrict__ H, int ldh) {
+  long total = (long)nd * nd;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % nd), j = (int)(e / nd);
+    if (i < j) continue;
+    int hi = hidx[i], hj = hidx[j];
+    int rr = hi > hj ? hi : hj, cc = hi > hj ? hj : hi;
+    H[(long)rr + (long)cc * ldh] += Hd[e];
+  }
+}
+
+// BGt[k + h*msz] = sum_e bval_e G[bcol_e + k*msz]     (one workgroup per H-row h)
+__global__ __launch_bounds__(256) void bg_kernel(const long* __restrict__ bptr, const int* __restrict__ bcol,
+                                                 const double* __restrict__ bval, const double* __restrict__ G,
+                                                 int msz, double* __restrict__ BGt) {
+  const int h = blockIdx.x;
+  const long b = bptr[h], e = bptr[h + 1];
+  for (int k = threadIdx.x; k < msz; k += 256) {
+    double s = 0.0;
+    for (long f = b; f < e; ++f) s += bval[f] * G[(long)bcol[f] + (long)k * msz];
+    BGt[(long)k + (long)h * msz] = s;
+  }
+}
+
+// H += C_lin diag(xs) C_lin'  (lower triangle), one workgroup per linear constraint
+__global__ __launch_bounds__(256) void lin_schur_kernel(const long* __restrict__ ptr, const int* __restrict__ row,
+                                                        const double* __restrict__ val, const double* __restrict__ xs,
+                                                        double* __restrict__ H, int ldh, int rank, int world,
+                                                        int bs) {
+  const int l = blockIdx.x;
+  const long b = ptr[l];
+  const int n = (int)(ptr[l + 1] - b);
+  const double d = xs[l];
+  for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+    int i = idx / n, j = idx - i * n;
+    int ri = row[b + i], rj = row[b + j];
+    if (ri < rj) continue;
+    if (world > 1 && (rj / bs) % world != rank) continue;
+    atomicAdd(&H[(long)ri + (long)rj * ldh], val[b + i] * val[b + j] * d);
+  }
+}
+
+__global__ void add_diag_kernel(double* __restrict__ H, int n, double eps) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) H[(long)i * n + i] += eps;
+}
+
+// natural-index full symmetric copy of the lower-authoritative H
+__global__ void export_h_kernel(const double* __restrict__ H, int n, const int* __restrict__ ipos,
+                                double* __restrict__ out) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    int hi = ipos ? ipos[i] : i, hj = ipos ? ipos[j] : j;
+    int rr = hi > hj ? hi : hj, cc = hi > hj ? hj : hi;
+    out[e] = H[(long)rr + (long)cc * n];
+  }
+}
+
+__global__ void gather_vec_kernel(const double* __restrict__ src, const int* __restrict__ idx, double* __restrict__ dst, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx ? idx[i] : i];
+}
+__global__ void scatter_vec_kernel(const double* __restrict__ src, const int* __restrict__ idx, double* __restrict__ dst, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[idx ? idx[i] : i] = src[i];
+}
+
+// ------------------------------------------------------------------ host drivers
+static long opt_t_batch = 0, opt_p_batch = 0;
+void set_batch_opts(long t, long p) {
+  if (t >= 0) opt_t_batch = t;
+  if (p >= 0) opt_p_batch = p;
+}
+
+static inline unsigned nblocks(long n, int per = 256, long cap = 4096) {
+  long b = (n + per - 1) / per;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
+  const int m = b.msz, nd = b.nd, n = c->nvar;
+  const long mm = (long)m * m;
+  double* W = b.W.as<double>();
+  double* Ad = b.Adense.as<double>();
+  double* H = c->H.as<double>();
+  // capacities
+  if (c->T_cap == 0 || c->P_cap == 0) {
+    size_t free_b = 0, total_b = 0;
+    LRN_HIP(c, hipMemGetInfo(&free_b, &total_b));
+    long pcap = opt_p_batch > 0 ? opt_p_batch : 32;
+    if (pcap > nd) pcap = nd;
+    double avail = (double)free_b * 0.80 - (double)pcap * mm * 8.0 - 1.5e9;
+    long tcap = (long)(avail / ((double)mm * 8.0));
+    if (opt_t_batch > 0) tcap = opt_t_batch;
+    if (tcap > nd) tcap = nd;
+    if (tcap < 1) return set_error(c, LRN_ERR_NOMEM, "not enough device memory for the T workspace");
+    LRN_TRY(ensure(c, c->P, (size_t)pcap * mm * 8));
+    LRN_TRY(ensure(c, c->T, (size_t)tcap * mm * 8, true));   // upper tiles stay zero forever
+    c->P_cap = pcap;
+    c->T_cap = tcap;
+  }
+  double* P = c->P.as<double>();
+  double* T = c->T.as<double>();
+  double* Hd = H;
+  long ldh = n;
+  if (!c->pos_space) {
+    LRN_TRY(ensure(c, c->Hd, (size_t)nd * nd * 8, true));
+    LRN_HIP(c, hipMemsetAsync(c->Hd.p, 0, (size_t)nd * nd * 8, c->stream));
+    Hd = c->Hd.as<double>();
+    ldh = nd;
+  }
+  // owner groups: contiguous slot ranges this rank owns, each at most T_cap long and
+  // starting on a 128 boundary (so that the triangular tile mask lines up)
+  std::vector<std::pair<int, int>> groups;
+  if (c->world > 1) {
+    for (int s0 = 0; s0 < nd; s0 += c->shard_bs)
+      if ((s0 / c->shard_bs) % c->world == c->rank) {
+        int s1 = std::min(nd, s0 + c->shard_bs);
+        for (int a = s0; a < s1; a += (int)c->T_cap) groups.push_back({a, std::min(s1, a + (int)c->T_cap)});
+      }
+  } else {
+    for (int s0 = 0; s0 < nd; s0 += (int)c->T_cap) groups.push_back({s0, std::min(nd, s0 + (int)c->T_cap)});
+  }
+  for (auto& g : groups) {
+    const int s0 = g.first, s1 = g.second, ns = s1 - s0;
+    for (int a = s0; a < s1; a += (int)c->P_cap) {
+      int nb = std::min((int)c->P_cap, s1 - a);
+      tic(c);
+      GemmDesc g1;   // P = A_a W
+      g1.A = Ad + (long)a * mm; g1.sAm = 1; g1.sAk = m; g1.bA = mm;
+      g1.B = W; g1.sBk = 1; g1.sBn = m; g1.bB = 0;
+      g1.C = P; g1.sCm = 1; g1.sCn = m; g1.bC = mm;
+      g1.M = g1.N = g1.K = m; g1.batch = nb;
+      LRN_TRY(gemm(c->stream, g1));
+      toc(c, "gemm1");
+      tic(c);
+      GemmDesc g2;   // T = W P, lower tiles, strictly-lower x2
+      g2.A = W; g2.sAm = 1; g2.sAk = m; g2.bA = 0;
+      g2.B = P; g2.sBk = 1; g2.sBn = m; g2.bB = mm;
+      g2.C = T + (long)(a - s0) * mm; g2.sCm = 1; g2.sCn = m; g2.bC = mm;
+      g2.M = g2.N = g2.K = m; g2.batch = nb;
+      g2.flags = GEMM_TRI_LOWER | GEMM_OFFDIAG_X2;
+      LRN_TRY(gemm(c->stream, g2));
+      toc(c, "gemm2");
+    }
+    // GEMM3: Hd[s0:nd, s0:s1] += A[s0:nd]^T . T   (packed-symmetric dot, lower tiles)
+    {
+      tic(c);
+      const int M = nd - s0, N = ns;
+      long tiles = 0;
+      int tM = (M + TS - 1) / TS, tN = (N + TS - 1) / TS;
+      for (int tn = 0; tn < tN; ++tn) tiles += std::max(0, tM - tn);
+      int ksplit = (int)std::min<long>(64, std::max<long>(1, (1536 + tiles - 1) / tiles));
+      ksplit = std::min(ksplit, std::max(1, m / 8));
+      size_t slab_bytes = (size_t)ksplit * M * N * 8;
+      LRN_TRY(ensure(c, c->slabs, slab_bytes));
+      GemmDesc g3;
+      g3.A = Ad + (long)s0 * mm; g3.sAm = mm; g3.sAk = 1;
+      g3.B = T; g3.sBk = 1; g3.sBn = mm;
+      g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
+      g3.M = M; g3.N = N;
+      g3.flags = GEMM_TRI_LOWER | GEMM_KSEG_TRI;
+      g3.kseg_ld = m; g3.kseg_cols = m;
+      g3.ksplit = ksplit; g3.sCs = (long)M * N;
+      LRN_TRY(gemm(c->stream, g3));
+      hipLaunchKernelGGL(reduce_slabs_tri_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,
+                         c->slabs.as<double>(), (long)M * N, ksplit, M, N, Hd + (long)s0 + (long)s0 * ldh, ldh);
+      toc(c, "gemm3");
+    }
+    // dense owner x sparse other
+    if (b.npos_nz > nd) {
+      tic(c);
+      int nsp = b.npos_nz - nd;
+      for (int y0 = 0; y0 < ns; y0 += 32768) {
+        int ny = std::min(32768, ns - y0);
+        hipLaunchKernelGGL(dense_sparse_gather_kernel, dim3((nsp + 255) / 256, ny), dim3(256), 0, c->stream,
+                           b.ent_ptr.as<long>(), b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(),
+                           T + (long)y0 * mm, m, s0 + y0, ny, nd, b.npos_nz, b.hidx.as<int>(), H, n);
+      }
+      toc(c, "sparse");
+    }
+  }
+  if (!c->pos_space)
+    hipLaunchKernelGGL(scatter_add_lower_kernel, dim3(nblocks((long)nd * nd)), dim3(256), 0, c->stream, Hd, nd,
+                       b.hidx.as<int>(), H, n);
+  return LRN_OK;
+}
+
+static int assemble_sparse(lrn_ctx* c, LmiBlock& b) {
+  const int n = c->nvar;
+  double* H = c->H.as<double>();
+  tic(c);
+  if (b.q_wave > b.nd) {
+    int nown = b.q_wave - b.nd;
+    int noth = b.npos_nz - b.nd;
+    for (int y0 = 0; y0 < nown; y0 += 32768) {
+      int ny = std::min(32768, nown - y0);
+      hipLaunchKernelGGL(pair_wave_kernel, dim3((noth - y0 + 3) / 4, ny), dim3(256), 0, c->stream,
+                         b.ent_ptr.as<long>(), b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(),
+                         b.W.as<double>(), b.msz, b.nd + y0, b.q_wave, b.npos_nz, b.hidx.as<int>(), H, n,
+                         c->rank, c->world, c->shard_bs);
+    }
+  }
+  if (b.npos_nz > b.q_wave) {
+    int nown = b.npos_nz - b.q_wave;
+    for (int y0 = 0; y0 < nown; y0 += 32768) {
+      int ny = std::min(32768, nown - y0);
+      hipLaunchKernelGGL(pair_thread_kernel, dim3((nown - y0 + 255) / 256, ny), dim3(256), 0, c->stream,
+                         b.ent_ptr.as<long>(), b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(),
+                         b.W.as<double>(), b.msz, b.q_wave + y0, b.npos_nz, b.hidx.as<int>(), H, n, c->rank,
+                         c->world, c->shard_bs);
+    }
+  }
+  toc(c, "sparse");
+  return LRN_OK;
+}
+
+static int assemble_rank1(lrn_ctx* c, LmiBlock& b) {
+  const int n = c->nvar, m = b.msz;
+  if (!b.has_B) return set_error(c, LRN_ERR_STATE, "rank-one mode requested but no B factors were uploaded");
+  if (!b.have_G) return set_error(c, LRN_ERR_STATE, "rank-one mode needs G (lrn_prepare_w / lrn_set_scaling)");
+  LRN_TRY(ensure(c, c->BG, (size_t)m * n * 8));
+  tic(c);
+  hipLaunchKernelGGL(bg_kernel, dim3(n), dim3(256), 0, c->stream, b.b_ptr.as<long>(), b.b_col.as<int>(),
+                     b.b_val.as<double>(), b.G.as<double>(), m, c->BG.as<double>());
+  GemmDesc g;
+  g.A = c->BG.as<double>(); g.sAm = m; g.sAk = 1;
+  g.B = c->BG.as<double>(); g.sBk = 1; g.sBn = m;
+  g.C = c->H.as<double>(); g.sCm = 1; g.sCn = n;
+  g.M = g.N = n; g.K = m;
+  g.beta = 1.0;
+  g.flags = GEMM_TRI_LOWER | GEMM_SQUARE;
+  LRN_TRY(gemm(c->stream, g));
+  toc(c, "rank1");
+  return LRN_OK;
+}
+
+int schur_assemble(lrn_ctx* c, int mode) {
+  const int n = c->nvar;
+  if (n <= 0) return set_error(c, LRN_ERR_STATE, "no model uploaded");
+  hipEvent_t a0, a1;
+  if (c->profile) {
+    (void)hipEventCreate(&a0);
+    (void)hipEventCreate(&a1);
+    (void)hipEventRecord(a0, c->stream);
+  }
+  LRN_HIP(c, hipMemsetAsync(c->H.p, 0, (size_t)n * n * 8, c->stream));
+  for (auto& b : c->lmi) {
+    if (mode == -1) {
+      LRN_TRY(assemble_rank1(c, b));
+      continue;
+    }
+    if (!b.have_W) return set_error(c, LRN_ERR_STATE, "W not set (call lrn_prepare_w or lrn_set_scaling)");
+    if (b.nd > 0) LRN_TRY(assemble_dense(c, b));
+    if (b.npos_nz > b.nd) LRN_TRY(assemble_sparse(c, b));
+  }
+  if (c->nlin > 0) {
+    tic(c);
+    hipLaunchKernelGGL(lin_schur_kernel, dim3(c->nlin), dim3(256), 0, c->stream, c->cl_ptr.as<long>(),
+                       c->cl_row.as<int>(), c->cl_val.as<double>(), c->lin_xs.as<double>(), c->H.as<double>(), n,
+                       c->rank, c->world, c->shard_bs);
+    toc(c, "lin");
+  }
+  if (c->profile) {
+    (void)hipEventRecord(a1, c->stream);
+    (void)hipEventSynchronize(a1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["assemble"] += ms;
+    c->counts["assemble"] += 1;
+    (void)hipEventDestroy(a0);
+    (void)hipEventDestroy(a1);
+  }
+  LRN_HIP(c, hipGetLastError());
+  c->have_H = true;
+  c->have_L = false;
+  return LRN_OK;
+}
+
+int schur_add_diag(lrn_ctx* c, double eps) {
+  if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  hipLaunchKernelGGL(add_diag_kernel, dim3((c->nvar + 255) / 256), dim3(256), 0, c->stream, c->H.as<double>(),
+                     c->nvar, eps);
+  c->have_L = false;
+  return LRN_OK;
+}
+
+int schur_get(lrn_ctx* c, double* Hout) {
+  if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  const int n = c->nvar;
+  size_t bytes = (size_t)n * n * 8;
+  LRN_TRY(ensure(c, c->slabs, bytes));     // assembly scratch doubles as staging
+  const int* ipos = c->pos_space ? c->lmi[0].ipos_d.as<int>() : nullptr;
+  hipLaunchKernelGGL(export_h_kernel, dim3(nblocks((long)n * n)), dim3(256), 0, c->stream, c->H.as<double>(), n,
+                     ipos, c->slabs.as<double>());
+  return copy_out(c, Hout, c->slabs.p, bytes);
+}
+
+int schur_factor(lrn_ctx* c, int* info) {
+  if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  const int n = c->nvar;
+  size_t bytes = (size_t)n * n * 8;
+  LRN_TRY(ensure(c, c->L, bytes));
+  LRN_TRY(ensure(c, c->Linv, chol_linv_doubles(n) * 8));
+  LRN_TRY(ensure(c, c->cholwork, (size_t)n * CHOL_NB * 8));
+  hipEvent_t a0, a1;
+  if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
+  LRN_HIP(c, hipMemcpyAsync(c->L.p, c->H.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+  LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, c->stream));
+  LRN_TRY(potrf_lower(c->stream, c->L.as<double>(), n, n, c->Linv.as<double>(), c->cholwork.as<double>(),
+                      c->info_dev.as<int>()));
+  int h_info = 0;
+  LRN_HIP(c, hipMemcpyAsync(&h_info, c->info_dev.p, 4, hipMemcpyDeviceToHost, c->stream));
+  if (c->profile) { (void)hipEventRecord(a1, c->stream); }
+  LRN_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->profile) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["factor"] += ms; c->counts["factor"] += 1;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+  }
+  if (info) *info = h_info;
+  c->have_L = (h_info == 0);
+  return LRN_OK;
+}
+
+int schur_solve(lrn_ctx* c, const double* h, double* dely) {
+  if (!c->have_L) return set_error(c, LRN_ERR_STATE, "no factor (call lrn_schur_factor)");
+  const int n = c->nvar;
+  hipEvent_t a0, a1;
+  LRN_TRY(copy_in(c, c->v0.p, h, (size_t)n * 8));
+  if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
+  const int* sig = c->pos_space ? c->lmi[0].sigma_d.as<int>() : nullptr;
+  unsigned nb = (unsigned)((n + 255) / 256);
+  // position space: hs[p] = h[sigma[p]]
+  hipLaunchKernelGGL(gather_vec_kernel, dim3(nb), dim3(256), 0, c->stream, c->v0.as<double>(), sig, c->v1.as<double>(), n);
+  LRN_TRY(potrs_vec(c->stream, c->L.as<double>(), n, n, c->Linv.as<double>(), c->v1.as<double>(), c->v0.as<double>(),
+                    c->v2.as<double>(), c->v3.as<double>()));
+  hipLaunchKernelGGL(scatter_vec_kernel, dim3(nb), dim3(256), 0, c->stream, c->v0.as<double>(), sig, c->v1.as<double>(), n);
+  if (c->profile) {
+    (void)hipEventRecord(a1, c->stream);
+    (void)hipEventSynchronize(a1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["solve"] += ms; c->counts["solve"] += 1;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+  }
+  return copy_out(c, dely, c->v1.p, (size_t)n * 8);
+}
+
+}  // namespace lrn
