@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- ms per IP iteration (Schur assembly + solve) on the BASELINE metric config:
+synthetic dense SDP, matrix side 2000, 4000 constraints (SURVEY.md section 8d "C4"),
+kit=0, FP64, data generated on the device (128 GB of constraint matrices).
+
+One "step" = one pass of the hot path over one iterate: assemble H (GEMM1/2/3 on the FP64
+MFMA), factor it (blocked Cholesky) and run the predictor and corrector solves.  Inputs
+(constraint data, NT scaling W, right-hand sides) are resident in HBM when the timed region
+starts.  N > 1: one process per GPU (torchrun), Schur column blocks sharded block-cyclically,
+RCCL all-gather of the owned blocks before the factorisation; total work is fixed
+(`"scaling": "strong"`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--msz 2000] [--nvar 4000]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # AMD datasheet, MI355X FP64 matrix; the
+#                                  local microarch guide has no FP64 MFMA row -- the measured
+#                                  issue-rate probe is reported next to it as `peak_probe`.
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--msz", type=int, default=2000)
+    ap.add_argument("--nvar", type=int, default=4000)
+    ap.add_argument("--seed", type=int, default=20250614)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-msz", type=int, default=300)
+    ap.add_argument("--cpu-nvar", type=int, default=400)
+    return ap.parse_args()
+
+
+def flops_model(msz, nvar):
+    """algorithmic work of one kit=0 IP iteration on dense data."""
+    return 4.0 * nvar * msz ** 3 + float(nvar) ** 2 * msz ** 2 + nvar ** 3 / 3.0 + 8.0 * nvar ** 2
+
+
+def make_scaling(msz, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((msz, msz)) / np.sqrt(msz) + np.eye(msz)
+    return G @ G.T, G
+
+
+def cpu_baseline(msz, nvar, seed):
+    """The CPU restatement of the reference path (oracle, kind 'port') timed on the host cores
+    on a bounded sample of the same workload, plus the GPU path on the very same sample."""
+    import numpy as np
+    import scipy.sparse as sp
+    from oracle import loraine_oracle as lo
+    import loraine_jl_amd
+    rng = np.random.default_rng(seed)
+    A = [[sp.csc_matrix((msz, msz))]]
+    for _ in range(nvar):
+        R = rng.standard_normal((msz, msz))
+        A[0].append(sp.csc_matrix((R + R.T) / 2))
+    model = lo.make_model(A, rng.standard_normal(nvar), 0.0, None, None)
+    W, G = make_scaling(msz, seed + 1)
+    h1, h2 = rng.standard_normal(nvar), rng.standard_normal(nvar)
+    import scipy.linalg as sla
+    t0 = time.perf_counter()
+    H = lo.makeBBBBs(model.n, 1, model.A, model.AA, [W], model.qA, model.sigmaA)
+    Hl = np.tril(H)
+    L = np.linalg.cholesky(Hl + np.tril(Hl, -1).T)
+    for h in (h1, h2):
+        x = sla.solve_triangular(L.T, sla.solve_triangular(L, h, lower=True), lower=False)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    dev = loraine_jl_amd.Device(0)
+    dev.set_option("dense_threshold", 1)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    dev.set_option("dense_threshold", -1)
+    dev.set_scaling(0, W, G)
+    import torch
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dev.schur_assemble(0)
+        assert dev.schur_factor() == 0
+        xg = dev.schur_solve(h1)
+        xg = dev.schur_solve(h2)
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) * 1e3
+    err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
+    dev.close()
+    fl = flops_model(msz, nvar)
+    return {
+        "value": cpu_ms, "unit": "ms/IP-iteration (Schur assembly + solve) on the sample instance",
+        "cores": os.cpu_count(), "kind": "port",
+        "sample": f"same generator, dense SDP matrix side {msz}, {nvar} constraints "
+                  f"({fl / 1e9:.1f} GFLOP algorithmic); CPU = NumPy/SciPy restatement of the reference path "
+                  f"(OpenBLAS GEMM threads = all host cores, SciPy SpMV single-threaded)",
+        "cpu_gflops": fl / cpu_ms / 1e6,
+        "gpu_ms_same_sample": gpu_ms,
+        "gpu_vs_cpu_rel_err_dely": err,
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import loraine_jl_amd
+    dev = loraine_jl_amd.Device(local_rank)
+    msz, nvar = args.msz, args.nvar
+    t0 = time.perf_counter()
+    dev.synthetic_dense_model(msz, nvar, args.seed)
+    t_gen = time.perf_counter() - t0
+    W, G = make_scaling(msz, args.seed + 1)
+    dev.set_scaling(0, W, G)
+    rng = np.random.default_rng(args.seed + 2)
+    h_pred = torch.from_numpy(rng.standard_normal(nvar)).cuda()
+    h_corr = torch.from_numpy(rng.standard_normal(nvar)).cuda()
+    dely = torch.zeros(nvar, dtype=torch.float64, device="cuda")
+    if world > 1:
+        dev.set_shard(rank, world)
+        shard = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
+        gathered = torch.zeros(dev.shard_doubles() * world, dtype=torch.float64, device="cuda")
+    from loraine_jl_amd._capi import ptr
+    lib = dev.lib
+
+    def step():
+        dev.schur_assemble(0)                                   # makeBBBBs on the owned columns
+        if world > 1:
+            dev.schur_export_shard(shard)
+            dist.all_gather_into_tensor(gathered, shard)        # RCCL over xGMI
+            torch.cuda.current_stream().synchronize()
+            dev.schur_import_all(gathered)
+        info = dev.schur_factor()                               # cholesky(BBBB)
+        assert info == 0, f"Schur matrix not PD (info={info})"
+        dev._chk(lib.lrn_schur_solve(dev.h, ptr(h_pred), ptr(dely)), "solve")   # predictor
+        dev._chk(lib.lrn_schur_solve(dev.h, ptr(h_corr), ptr(dely)), "solve")   # corrector
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dev.set_option("profile", 0)
+    for _ in range(args.warmup):
+        step()
+    dev.set_option("profile", 1)          # per-kernel HIP-event timing on the library's stream
+    dev.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        # dominant kernel: GEMM1  P_k = A_k W  (gemm_f64_kernel<128,128,...>, batched)
+        n1 = max(1, dev.count("gemm1"))
+        t1 = dev.timing("gemm1") / n1                               # ms per launch (HIP events)
+        nown = nvar if world == 1 else sum(min(nvar, (b + 1) * 128) - b * 128
+                                           for b in range((nvar + 127) // 128) if b % world == rank)
+        launches_per_step = n1 / args.steps
+        units_per_launch = nown / launches_per_step                 # constraint matrices per launch
+        alg_flops_launch = 2.0 * msz ** 3 * units_per_launch
+        achieved = alg_flops_launch / (t1 * 1e-3) / 1e12
+        probe = dev.mfma_f64_peak()
+        phases = {k: dev.timing(k) / args.steps for k in ("gemm1", "gemm2", "gemm3", "assemble", "factor", "solve")}
+        out = {
+            "metric": "ms/IP-iteration (Schur assembly + solve), dense SDP n=2000 m=4000",
+            "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C4 synthetic dense SDP, matrix side {msz}, {nvar} constraints, kit=0 "
+                                   f"(assembly + Cholesky + predictor/corrector solves)",
+                       "msz": msz, "nvar": nvar, "seed": args.seed,
+                       "parallelism": "1 GPU" if world == 1 else f"Schur column blocks over {world} GPUs + RCCL all-gather"},
+            "algorithmic_tflops": flops_model(msz, nvar) / (ms_per_step * 1e-3) / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128> GEMM1 P_k = A_k W (batched)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "peak_probe": probe, "avg_launch_ms": t1, "launches_per_step": launches_per_step},
+            "phase_ms_per_step": phases,
+            "data_gen_s": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            dev.close()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

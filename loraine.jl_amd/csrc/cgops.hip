@@ -1,0 +1,640 @@
+// CG operator, right-hand side, low-rank preconditioners and device-resident PCG.
+// Replaces MyA / MyM_no / MyM_beta / MyM, Prec_for_CG_beta, Prec_for_CG_tilS_prep,
+// prec_alpha_S! (reference src/Solvers.jl:572-904), makeRHS (src/makeBBBB.jl:221-228) and
+// cg of ConjugateGradients.jl 0.1 (call sites src/predictor_corrector.jl:134,235).
+//
+// Mat-vec  Ax = AA vec(W mat(AA' x) W):  AA' x is a deterministic gather over the stored
+// columns of AA (no atomics), the two msz^3 products run on the FP64 MFMA GEMM, AA vec(.)
+// is one wavefront per constraint.  All vectors live in natural constraint order.
+//
+// H_alpha apply uses the algebraically identical "ts" form of the SMW formula:
+//   ts = D^-1/2 AA (U (x) Z)   (nvar x k*msz, built once per IP iteration)
+//   M^-1 x = D^-1/2 [ v - ts (I + ts' ts)^-1 ts' v ],  v = D^-1/2 x
+// i.e. two bandwidth-bound GEMVs and one POTRS on the (k*msz)^2 factor -- this also covers
+// erank > 1 without materialising kron(Umat, Z) (Solvers.jl:759 would need msz^2 x k*msz).
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/loraine_hip.h"
+#include "ctx.h"
+#include "jacobi.h"
+
+namespace lrn {
+
+struct Prec {
+  int kind = 0, erank = 0, ksz = 0;
+  double dsum = 0.0;
+  DBuf d;        // nvar
+  DBuf ts;       // nvar x ksz
+  DBuf cholS, linvS, cw;
+  DBuf y, y2, y3, y4, zpart;
+  DBuf E, Um, AU, sig;
+};
+
+void prec_free(lrn_ctx* c) {
+  if (!c->prec) return;
+  Prec* p = c->prec;
+  for (DBuf* d : {&p->d, &p->ts, &p->cholS, &p->linvS, &p->cw, &p->y, &p->y2, &p->y3, &p->y4, &p->zpart, &p->E, &p->Um,
+                  &p->AU, &p->sig})
+    release(*d);
+  delete p;
+  c->prec = nullptr;
+}
+
+static inline unsigned nb(long n, long cap = 4096) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ------------------------------------------------------------------ AA' x  and  AA vec(Z)
+// M[q] = sum_k cq_v[k] * x[cq_j[k]] over the stored columns of AA (sparse constraints)
+__global__ void aat_gather_kernel(const long* __restrict__ cq_q, const long* __restrict__ cq_ptr,
+                                  const int* __restrict__ cq_j, const double* __restrict__ cq_v, long ncq,
+                                  const double* __restrict__ x, double* __restrict__ M) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncq; t += (long)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (long k = cq_ptr[t]; k < cq_ptr[t + 1]; ++k) s += cq_v[k] * x[cq_j[k]];
+    M[cq_q[t]] = s;
+  }
+}
+
+// M[q] -= sum_{p<nd} x[sigma[p]] * Adense[p][q]
+__global__ void aat_dense_kernel(const double* __restrict__ Ad, int nd, long mm, const int* __restrict__ sigma,
+                                 const double* __restrict__ x, double* __restrict__ M) {
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < mm; q += (long)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int p = 0; p < nd; ++p) s += x[sigma[p]] * Ad[(long)p * mm + q];
+    M[q] -= s;
+  }
+}
+
+// mat(): (M + M')/2 in place  (kron_etc.jl:13-18)
+__global__ void symmetrize_kernel(double* __restrict__ M, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    if (i < j) {
+      double a = M[e], b = M[(long)j + (long)i * n];
+      double s = (a + b) / 2.0;
+      M[e] = s;
+      M[(long)j + (long)i * n] = s;
+    }
+  }
+}
+
+// out[sigma[p]] += -sum_e a_e Z[r_e,c_e]   (one wavefront per sparse position)
+__global__ __launch_bounds__(256) void aa_times_kernel(const long* __restrict__ ptr, const int* __restrict__ er,
+                                                       const int* __restrict__ ec, const double* __restrict__ ev,
+                                                       const double* __restrict__ Z, int msz, int p_lo, int p_end,
+                                                       const int* __restrict__ sigma, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = p_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= p_end) return;
+  double s = 0.0;
+  for (long e = ptr[p] + lane; e < ptr[p + 1]; e += 64) s += ev[e] * Z[(long)er[e] + (long)ec[e] * msz];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) out[sigma[p]] -= s;
+}
+
+// out[sigma[p]] += -<Adense[p], Z>   (one workgroup per dense slot)
+__global__ __launch_bounds__(256) void aa_dense_dot_kernel(const double* __restrict__ Ad, long mm,
+                                                           const double* __restrict__ Z, const int* __restrict__ sigma,
+                                                           double* __restrict__ out) {
+  __shared__ double sh[4];
+  const double* a = Ad + (long)blockIdx.x * mm;
+  double s = 0.0;
+  for (long q = threadIdx.x; q < mm; q += 256) s += a[q] * Z[q];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[sigma[blockIdx.x]] -= sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// linear block: t_l = xs_l * sum_i C[i,l] x_i ; y_i += C[i,l] t_l
+__global__ void lin_matvec_kernel(const long* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
+                                  const double* __restrict__ xs, int nlin, const double* __restrict__ x,
+                                  double* __restrict__ y) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlin) return;
+  double t = 0.0;
+  for (long k = ptr[l]; k < ptr[l + 1]; ++k) t += val[k] * x[row[k]];
+  t *= xs[l];
+  for (long k = ptr[l]; k < ptr[l + 1]; ++k) atomicAdd(&y[row[k]], val[k] * t);
+}
+
+__global__ void lin_diag_kernel(const long* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
+                                const double* __restrict__ xs, int nlin, double* __restrict__ d) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlin) return;
+  for (long k = ptr[l]; k < ptr[l + 1]; ++k) atomicAdd(&d[row[k]], val[k] * val[k] * xs[l]);
+}
+
+static int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
+  const int m = b.msz;
+  GemmDesc g1;     // P = W M
+  g1.A = b.W.as<double>(); g1.sAm = 1; g1.sAk = m;
+  g1.B = M; g1.sBk = 1; g1.sBn = m;
+  g1.C = P; g1.sCm = 1; g1.sCn = m;
+  g1.M = g1.N = g1.K = m;
+  LRN_TRY(gemm(c->stream, g1));
+  GemmDesc g2;     // Z = P W
+  g2.A = P; g2.sAm = 1; g2.sAk = m;
+  g2.B = b.W.as<double>(); g2.sBk = 1; g2.sBn = m;
+  g2.C = Z; g2.sCm = 1; g2.sCn = m;
+  g2.M = g2.N = g2.K = m;
+  return gemm(c->stream, g2);
+}
+
+static int ensure_m(lrn_ctx* c, int m) {
+  size_t mm = (size_t)m * m * 8;
+  LRN_TRY(ensure(c, c->m0, mm));
+  LRN_TRY(ensure(c, c->m1, mm));
+  LRN_TRY(ensure(c, c->m2, mm));
+  return LRN_OK;
+}
+
+// y += AA vec(Z)
+static int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
+  if (b.npos_nz > b.nd)
+    hipLaunchKernelGGL(aa_times_kernel, dim3((b.npos_nz - b.nd + 3) / 4), dim3(256), 0, c->stream, b.ent_ptr.as<long>(),
+                       b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(), Z, b.msz, b.nd, b.npos_nz,
+                       b.sigma_d.as<int>(), y);
+  if (b.nd > 0)
+    hipLaunchKernelGGL(aa_dense_dot_kernel, dim3(b.nd), dim3(256), 0, c->stream, b.Adense.as<double>(),
+                       (long)b.msz * b.msz, Z, b.sigma_d.as<int>(), y);
+  return LRN_OK;
+}
+
+int matvec_dev(lrn_ctx* c, const double* x, double* y) {
+  const int n = c->nvar;
+  LRN_HIP(c, hipMemsetAsync(y, 0, (size_t)n * 8, c->stream));
+  for (auto& b : c->lmi) {
+    if (!b.have_W) return set_error(c, LRN_ERR_STATE, "W not set");
+    const int m = b.msz;
+    const long mm = (long)m * m;
+    LRN_TRY(ensure_m(c, m));
+    double* M = c->m0.as<double>();
+    LRN_HIP(c, hipMemsetAsync(M, 0, (size_t)mm * 8, c->stream));
+    if (b.ncq > 0)
+      hipLaunchKernelGGL(aat_gather_kernel, dim3(nb(b.ncq)), dim3(256), 0, c->stream, b.cq_q.as<long>(),
+                         b.cq_ptr.as<long>(), b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, M);
+    if (b.nd > 0)
+      hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>(), b.nd, mm,
+                         b.sigma_d.as<int>(), x, M);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, m);
+    LRN_TRY(wmw(c, b, M, c->m1.as<double>(), c->m2.as<double>()));
+    LRN_TRY(aa_times(c, b, c->m2.as<double>(), y));
+  }
+  if (c->nlin > 0)
+    hipLaunchKernelGGL(lin_matvec_kernel, dim3(nb(c->nlin)), dim3(256), 0, c->stream, c->cl_ptr.as<long>(),
+                       c->cl_rown.as<int>(), c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, x, y);
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
+// ------------------------------------------------------------------ vector kernels (single workgroup)
+__device__ __forceinline__ double wg_sum1024(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < 16; ++i) s += sh[i];
+  return s;
+}
+
+// scal: [0]=gamma [1]=pAp [2]=alpha [3]=rr [4]=flag(alpha invalid) [5]=beta [6]=||b|| [7]=zr
+__global__ __launch_bounds__(1024) void cg_norm_kernel(const double* __restrict__ b, int n, double* __restrict__ scal, int slot) {
+  __shared__ double sh[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += b[i] * b[i];
+  s = wg_sum1024(s, sh);
+  if (threadIdx.x == 0) scal[slot] = s;
+}
+
+__global__ __launch_bounds__(1024) void cg_alpha_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
+                                                        const double* __restrict__ z, double* __restrict__ r,
+                                                        double* __restrict__ x, int n, double* __restrict__ scal) {
+  __shared__ double sh[16];
+  double g = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) { g += r[i] * z[i]; q += p[i] * Ap[i]; }
+  g = wg_sum1024(g, sh);
+  q = wg_sum1024(q, sh);
+  double alpha = g / q;
+  bool bad = !(alpha >= 0.0) || isinf(alpha);
+  double rr = 0.0;
+  if (!bad)
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      x[i] += alpha * p[i];
+      double ri = r[i] - alpha * Ap[i];
+      r[i] = ri;
+      rr += ri * ri;
+    }
+  rr = wg_sum1024(rr, sh);
+  if (threadIdx.x == 0) { scal[0] = g; scal[1] = q; scal[2] = alpha; scal[3] = rr; scal[4] = bad ? 1.0 : 0.0; }
+}
+
+__global__ __launch_bounds__(1024) void cg_beta_kernel(const double* __restrict__ z, const double* __restrict__ r,
+                                                       double* __restrict__ p, int n, double* __restrict__ scal) {
+  __shared__ double sh[16];
+  double zr = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) zr += z[i] * r[i];
+  zr = wg_sum1024(zr, sh);
+  double beta = zr / scal[0];
+  for (int i = threadIdx.x; i < n; i += 1024) p[i] = z[i] + beta * p[i];
+  if (threadIdx.x == 0) { scal[5] = beta; scal[7] = zr; }
+}
+
+__global__ void div_kernel(const double* __restrict__ x, const double* __restrict__ d, double* __restrict__ y, int n, int sq) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] / (sq ? sqrt(d[i]) : d[i]);
+}
+
+__global__ void fill_kernel(double* __restrict__ d, int n, double v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = v;
+}
+
+// y[c] = sum_i ts[i + c*n] v[i]   (one workgroup per column)
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ ts, int n, const double* __restrict__ v,
+                                                     double* __restrict__ y) {
+  __shared__ double sh[4];
+  const double* col = ts + (long)blockIdx.x * n;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += col[i] * v[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) y[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// zpart[chunk][i] = sum_{c in chunk} ts[i + c*n] y[c]
+__global__ __launch_bounds__(256) void gemv_n_part_kernel(const double* __restrict__ ts, int n, int ncol, int cper,
+                                                          const double* __restrict__ y, double* __restrict__ zpart) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int c0 = blockIdx.y * cper, c1 = min(ncol, c0 + cper);
+  if (i >= n) return;
+  double s = 0.0;
+  for (int cc = c0; cc < c1; ++cc) s += ts[(long)i + (long)cc * n] * y[cc];
+  zpart[(long)blockIdx.y * n + i] = s;
+}
+
+// out = (v - sum_chunks zpart) / sqrt(d)
+__global__ void smw_final_kernel(const double* __restrict__ v, const double* __restrict__ zpart, int nchunk, int n,
+                                 const double* __restrict__ d, double* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nchunk; ++k) s += zpart[(long)k * n + i];
+  out[i] = (v[i] - s) / sqrt(d[i]);
+}
+
+// ------------------------------------------------------------------ H_alpha setup kernels
+// Um[:,a] = E[:,idx[a]] * coef[a]
+__global__ void umat_kernel(const double* __restrict__ E, int m, const int* __restrict__ idx,
+                            const double* __restrict__ coef, int k, double* __restrict__ Um) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m * k) return;
+  int i = e % m, a = e / m;
+  Um[e] = E[(long)i + (long)idx[a] * m] * coef[a];
+}
+
+// Zf = 2 W - Um Um'
+__global__ void zfull_kernel(const double* __restrict__ W, const double* __restrict__ Um, int m, int k,
+                             double* __restrict__ Zf) {
+  long total = (long)m * m;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % m), j = (int)(e / m);
+    double s = 0.0;
+    for (int a = 0; a < k; ++a) s += Um[i + a * m] * Um[j + a * m];
+    Zf[e] = 2.0 * W[e] - s;
+  }
+}
+
+__global__ void tril2_kernel(double* __restrict__ A, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    if ((int)(e % n) < (int)(e / n)) A[e] = 0.0;
+}
+
+// AU[j, r] += -a_e * Um[c, a] / sqrt(d_j), j = sigma[p]   (one thread per sparse position)
+__global__ void au_sparse_kernel(const long* __restrict__ ptr, const int* __restrict__ er, const int* __restrict__ ec,
+                                 const double* __restrict__ ev, int p_lo, int p_end, const int* __restrict__ sigma,
+                                 const double* __restrict__ Ucol, const double* __restrict__ d, int nvar,
+                                 double* __restrict__ AU) {
+  int p = p_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= p_end) return;
+  int j = sigma[p];
+  double sc = -1.0 / sqrt(d[j]);
+  for (long e = ptr[p]; e < ptr[p + 1]; ++e) AU[(long)j + (long)er[e] * nvar] += sc * ev[e] * Ucol[ec[e]];
+}
+
+// dense slot p: AU[sigma[p], r] = -(A_p u)[r] / sqrt(d)
+__global__ __launch_bounds__(256) void au_dense_kernel(const double* __restrict__ Ad, int m, const int* __restrict__ sigma,
+                                                       const double* __restrict__ Ucol, const double* __restrict__ d,
+                                                       int nvar, double* __restrict__ AU) {
+  const double* A = Ad + (long)blockIdx.x * m * m;
+  int j = sigma[blockIdx.x];
+  double sc = -1.0 / sqrt(d[j]);
+  for (int r = threadIdx.x; r < m; r += 256) {
+    double s = 0.0;
+    for (int cidx = 0; cidx < m; ++cidx) s += A[(long)r + (long)cidx * m] * Ucol[cidx];
+    AU[(long)j + (long)r * nvar] = sc * s;
+  }
+}
+
+__global__ void add_eye_kernel(double* __restrict__ S, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) S[(long)i * n + i] += 1.0;
+}
+
+static double tau_of(const std::vector<double>& lam_s, int aamat) {
+  // Solvers.jl:646-650 / :715-719
+  double mn = lam_s[0], mean = 0.0;
+  for (double v : lam_s) { mn = std::min(mn, v); mean += v; }
+  mean /= (double)lam_s.size();
+  if (aamat == 0) return 1.0 * mn;
+  return (mn + mean) / 2.0 - 1.0e-14;
+}
+
+int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
+  if (info) *info = 0;
+  if (!c->prec) c->prec = new Prec();
+  Prec* P = c->prec;
+  P->kind = kind;
+  P->erank = erank;
+  const int n = c->nvar;
+  hipStream_t st = c->stream;
+  if (kind == 0) return LRN_OK;
+  if (kind != 1 && kind != 2) return set_error(c, LRN_ERR_ARG, "preconditioner %d not supported", kind);
+  if (c->nlmi < 1) return set_error(c, LRN_ERR_STATE, "preconditioner needs at least one LMI block");
+  if (kind == 1 && c->nlin > 0)
+    return set_error(c, LRN_ERR_STATE, "H_alpha with linear constraints needs a sparse solve (out of scope, SURVEY 2.2)");
+  hipEvent_t a0, a1;
+  if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, st); }
+  int ksz = 0;
+  for (auto& b : c->lmi) ksz += erank * b.msz;
+  P->ksz = ksz;
+  LRN_TRY(ensure(c, P->d, (size_t)n * 8));
+  double dsum = 0.0;
+  struct BlkEig { std::vector<int> idx; std::vector<double> coef; double tau; };
+  std::vector<BlkEig> be(c->nlmi);
+  for (int il = 0; il < c->nlmi; ++il) {
+    LmiBlock& b = c->lmi[il];
+    const int m = b.msz, k = erank;
+    if (!b.have_G) return set_error(c, LRN_ERR_STATE, "preconditioner setup needs G (lrn_prepare_w)");
+    if (k >= m) return set_error(c, LRN_ERR_ARG, "erank >= matrix size");
+    size_t mm = (size_t)m * m * 8;
+    LRN_TRY(ensure(c, P->E, mm));
+    LRN_TRY(ensure(c, P->sig, (size_t)m * 8));
+    LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
+    int sweeps = 0;
+    // eig(W) = svd(G)^2 : columns of E become sigma_j u_j   (Solvers.jl:642,706)
+    LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sweeps));
+    std::vector<double> sg(m);
+    LRN_TRY(copy_out(c, sg.data(), P->sig.p, (size_t)m * 8));
+    std::vector<int> ord(m);
+    for (int i = 0; i < m; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sg[x] < sg[y]; });   // ascending
+    std::vector<double> lam_s(m - k);
+    for (int i = 0; i < m - k; ++i) lam_s[i] = sg[ord[i]] * sg[ord[i]];
+    double tau = tau_of(lam_s, aamat);
+    be[il].tau = tau;
+    if (aamat < 3) dsum += tau * tau;
+    be[il].idx.resize(k);
+    be[il].coef.resize(k);
+    for (int a = 0; a < k; ++a) {
+      int id = ord[m - k + a];
+      double lam = sg[id] * sg[id];
+      be[il].idx[a] = id;
+      be[il].coef[a] = std::sqrt(std::max(lam - tau, 0.0)) / sg[id];   // Umat = v_l sqrt(lambda_l - tau)
+    }
+    if (kind == 2) continue;
+  }
+  P->dsum = dsum;
+  hipLaunchKernelGGL(fill_kernel, dim3(nb(n)), dim3(256), 0, st, P->d.as<double>(), n, dsum);
+  if (c->nlin > 0)
+    hipLaunchKernelGGL(lin_diag_kernel, dim3(nb(c->nlin)), dim3(256), 0, st, c->cl_ptr.as<long>(), c->cl_rown.as<int>(),
+                       c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, P->d.as<double>());
+  if (kind == 1) {
+    LRN_TRY(ensure(c, P->ts, (size_t)n * ksz * 8));
+    int col0 = 0;
+    for (int il = 0; il < c->nlmi; ++il) {
+      LmiBlock& b = c->lmi[il];
+      const int m = b.msz, k = erank;
+      size_t mm = (size_t)m * m * 8;
+      // eigenvectors again (E was overwritten by later blocks only when nlmi > 1)
+      if (c->nlmi > 1) {
+        LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
+        int sw = 0;
+        LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sw));
+      }
+      LRN_TRY(ensure(c, P->Um, (size_t)m * k * 8 + (size_t)k * 16));
+      double* Um = P->Um.as<double>();
+      double* coef_d = Um + (size_t)m * k;
+      int* idx_d = reinterpret_cast<int*>(coef_d + k);
+      LRN_TRY(copy_in(c, coef_d, be[il].coef.data(), (size_t)k * 8));
+      LRN_TRY(copy_in(c, idx_d, be[il].idx.data(), (size_t)k * 4));
+      hipLaunchKernelGGL(umat_kernel, dim3(nb((long)m * k)), dim3(256), 0, st, P->E.as<double>(), m, idx_d, coef_d, k, Um);
+      // Z = chol(2 W0 + Um Um') = chol(2W - Um Um')   (Solvers.jl:725-731)
+      LRN_TRY(ensure_m(c, m));
+      double* Zf = c->m0.as<double>();
+      hipLaunchKernelGGL(zfull_kernel, dim3(nb((long)m * m)), dim3(256), 0, st, b.W.as<double>(), Um, m, k, Zf);
+      LRN_TRY(ensure(c, P->linvS, chol_linv_doubles(std::max(m, ksz)) * 8));
+      LRN_TRY(ensure(c, P->cw, (size_t)std::max(m, ksz) * CHOL_NB * 8));
+      LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, st));
+      LRN_TRY(potrf_lower(st, Zf, m, m, P->linvS.as<double>(), P->cw.as<double>(), c->info_dev.as<int>()));
+      int h = 0;
+      LRN_TRY(copy_out(c, &h, c->info_dev.p, 4));
+      if (h != 0) { if (info) *info = h; return LRN_OK; }
+      hipLaunchKernelGGL(tril2_kernel, dim3(nb((long)m * m)), dim3(256), 0, st, Zf, m);
+      // ts[:, block a] = (D^-1/2 AU_a) Z
+      LRN_TRY(ensure(c, P->AU, (size_t)n * m * 8));
+      for (int a = 0; a < k; ++a) {
+        LRN_HIP(c, hipMemsetAsync(P->AU.p, 0, (size_t)n * m * 8, st));
+        const double* Ucol = Um + (size_t)a * m;
+        if (b.npos_nz > b.nd)
+          hipLaunchKernelGGL(au_sparse_kernel, dim3(nb(b.npos_nz - b.nd)), dim3(256), 0, st, b.ent_ptr.as<long>(),
+                             b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(), b.nd, b.npos_nz,
+                             b.sigma_d.as<int>(), Ucol, P->d.as<double>(), n, P->AU.as<double>());
+        if (b.nd > 0)
+          hipLaunchKernelGGL(au_dense_kernel, dim3(b.nd), dim3(256), 0, st, b.Adense.as<double>(), m, b.sigma_d.as<int>(),
+                             Ucol, P->d.as<double>(), n, P->AU.as<double>());
+        GemmDesc g;
+        g.A = P->AU.as<double>(); g.sAm = 1; g.sAk = n;
+        g.B = Zf; g.sBk = 1; g.sBn = m;
+        g.C = P->ts.as<double>() + (size_t)(col0 + a * m) * n; g.sCm = 1; g.sCn = n;
+        g.M = n; g.N = m; g.K = m;
+        LRN_TRY(gemm(st, g));
+      }
+      col0 += k * m;
+    }
+    // S = ts' ts + I ; cholS   (Solvers.jl:804-805)
+    LRN_TRY(ensure(c, P->cholS, (size_t)ksz * ksz * 8));
+    GemmDesc g;
+    g.A = P->ts.as<double>(); g.sAm = n; g.sAk = 1;
+    g.B = P->ts.as<double>(); g.sBk = 1; g.sBn = n;
+    g.C = P->cholS.as<double>(); g.sCm = 1; g.sCn = ksz;
+    g.M = g.N = ksz; g.K = n;
+    g.flags = GEMM_TRI_LOWER;
+    LRN_TRY(gemm(st, g));
+    hipLaunchKernelGGL(add_eye_kernel, dim3(nb(ksz)), dim3(256), 0, st, P->cholS.as<double>(), ksz);
+    LRN_TRY(ensure(c, P->linvS, chol_linv_doubles(ksz) * 8));
+    LRN_TRY(ensure(c, P->cw, (size_t)ksz * CHOL_NB * 8));
+    LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, st));
+    LRN_TRY(potrf_lower(st, P->cholS.as<double>(), ksz, ksz, P->linvS.as<double>(), P->cw.as<double>(),
+                        c->info_dev.as<int>()));
+    int h = 0;
+    LRN_TRY(copy_out(c, &h, c->info_dev.p, 4));
+    if (h != 0) { if (info) *info = h; return LRN_OK; }
+    LRN_TRY(ensure(c, P->y, (size_t)(ksz + 64) * 8));
+    LRN_TRY(ensure(c, P->y2, (size_t)(ksz + 64) * 8));
+    LRN_TRY(ensure(c, P->y3, (size_t)(ksz + 64) * 8));
+    LRN_TRY(ensure(c, P->y4, (size_t)(ksz + 64) * 8));
+    LRN_TRY(ensure(c, P->zpart, (size_t)32 * n * 8));
+  }
+  if (c->profile) {
+    (void)hipEventRecord(a1, st); (void)hipEventSynchronize(a1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["prec_setup"] += ms; c->counts["prec_setup"] += 1;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+  }
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
+// Mx = M^-1 x, device vectors; tmpv: nvar scratch
+int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
+  Prec* P = c->prec;
+  const int n = c->nvar;
+  hipStream_t st = c->stream;
+  if (!P || P->kind == 0) {                                  // MyM_no  (Solvers.jl:620-622)
+    LRN_HIP(c, hipMemcpyAsync(Mx, x, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    return LRN_OK;
+  }
+  if (P->kind == 2) {                                        // MyM_beta (Solvers.jl:670-672)
+    hipLaunchKernelGGL(div_kernel, dim3(nb(n)), dim3(256), 0, st, x, P->d.as<double>(), Mx, n, 0);
+    return LRN_OK;
+  }
+  const int ksz = P->ksz;                                    // MyM (Solvers.jl:866-904), ts form
+  hipLaunchKernelGGL(div_kernel, dim3(nb(n)), dim3(256), 0, st, x, P->d.as<double>(), tmpv, n, 1);
+  hipLaunchKernelGGL(gemv_t_kernel, dim3(ksz), dim3(256), 0, st, P->ts.as<double>(), n, tmpv, P->y.as<double>());
+  LRN_TRY(potrs_vec(st, P->cholS.as<double>(), ksz, ksz, P->linvS.as<double>(), P->y.as<double>(), P->y2.as<double>(),
+                    P->y3.as<double>(), P->y4.as<double>()));
+  const int nchunk = std::min(32, std::max(1, ksz / 32));
+  const int cper = (ksz + nchunk - 1) / nchunk;
+  hipLaunchKernelGGL(gemv_n_part_kernel, dim3((n + 255) / 256, nchunk), dim3(256), 0, st, P->ts.as<double>(), n, ksz,
+                     cper, P->y2.as<double>(), P->zpart.as<double>());
+  hipLaunchKernelGGL(smw_final_kernel, dim3(nb(n)), dim3(256), 0, st, tmpv, P->zpart.as<double>(), nchunk, n,
+                     P->d.as<double>(), Mx);
+  return LRN_OK;
+}
+
+// cg(A, b; tol, maxIter, precon) -- restates ConjugateGradients.jl 0.1 (see oracle.cg)
+int pcg_dev(lrn_ctx* c, const double* b, double tol, int maxit, double* x, int* exit_code, int* iters) {
+  const int n = c->nvar;
+  hipStream_t st = c->stream;
+  LRN_TRY(ensure(c, c->cgbuf, (size_t)(6 * (size_t)n + 64) * 8));
+  double* r = c->cgbuf.as<double>();
+  double* z = r + n;
+  double* p = z + n;
+  double* Ap = p + n;
+  double* tmpv = Ap + n;
+  double* scal = tmpv + n;          // 16 doubles
+  double hs[8];
+  long nmv = 0;
+  LRN_HIP(c, hipMemsetAsync(x, 0, (size_t)n * 8, st));
+  hipLaunchKernelGGL(cg_norm_kernel, dim3(1), dim3(1024), 0, st, b, n, scal, 6);
+  LRN_HIP(c, hipMemcpyAsync(hs, scal + 6, 8, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipStreamSynchronize(st));
+  if (std::sqrt(hs[0]) == 0.0) { *exit_code = 1; *iters = 0; return LRN_OK; }
+  // r = b - A*0 = b
+  LRN_HIP(c, hipMemcpyAsync(r, b, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  const double residual_0 = std::sqrt(hs[0]);
+  if (residual_0 <= tol) { *exit_code = 2; *iters = 0; return LRN_OK; }
+  LRN_TRY(prec_apply_dev(c, r, z, tmpv));
+  LRN_HIP(c, hipMemcpyAsync(p, z, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  for (int it = 1; it <= maxit; ++it) {
+    LRN_TRY(matvec_dev(c, p, Ap));
+    ++nmv;
+    hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1024), 0, st, p, Ap, z, r, x, n, scal);
+    LRN_HIP(c, hipMemcpyAsync(hs, scal, 5 * 8, hipMemcpyDeviceToHost, st));
+    LRN_HIP(c, hipStreamSynchronize(st));
+    if (hs[4] != 0.0) { *exit_code = -13; *iters = it; c->counts["matvec"] += nmv; return LRN_OK; }
+    double residual = std::sqrt(hs[3]) / residual_0;
+    if (residual <= tol) { *exit_code = 30; *iters = it; c->counts["matvec"] += nmv; return LRN_OK; }
+    LRN_TRY(prec_apply_dev(c, r, z, tmpv));
+    hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1024), 0, st, z, r, p, n, scal);
+  }
+  *exit_code = -2;
+  *iters = maxit;
+  c->counts["matvec"] += nmv;
+  return LRN_OK;
+}
+
+}  // namespace lrn
+
+using namespace lrn;
+
+extern "C" int lrn_matvec(lrn_ctx* c, const double* x, double* Ax) {
+  if (!c || !x || !Ax) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_TRY(copy_in(c, c->v0.p, x, (size_t)n * 8));
+  tic(c);
+  LRN_TRY(matvec_dev(c, c->v0.as<double>(), c->v1.as<double>()));
+  toc(c, "matvec");
+  return copy_out(c, Ax, c->v1.p, (size_t)n * 8);
+}
+
+extern "C" int lrn_make_rhs(lrn_ctx* c, const double* Rp, const double* const* RdS, double* h) {
+  if (!c || !Rp || !h || (c->nlmi > 0 && !RdS)) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_TRY(copy_in(c, c->v1.p, Rp, (size_t)n * 8));
+  for (int il = 0; il < c->nlmi; ++il) {
+    LmiBlock& b = c->lmi[il];
+    if (!b.have_W) return set_error(c, LRN_ERR_STATE, "W not set");
+    LRN_TRY(ensure_m(c, b.msz));
+    LRN_TRY(copy_in(c, c->m0.p, RdS[il], (size_t)b.msz * b.msz * 8));
+    LRN_TRY(wmw(c, b, c->m0.as<double>(), c->m1.as<double>(), c->m2.as<double>()));
+    LRN_TRY(aa_times(c, b, c->m2.as<double>(), c->v1.as<double>()));
+  }
+  return copy_out(c, h, c->v1.p, (size_t)n * 8);
+}
+
+extern "C" int lrn_prec_setup(lrn_ctx* c, int prec, int erank, int aamat, int* info) {
+  if (!c) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  return prec_setup(c, prec, erank, aamat, info);
+}
+
+extern "C" int lrn_prec_apply(lrn_ctx* c, const double* x, double* Mx) {
+  if (!c || !x || !Mx) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_TRY(copy_in(c, c->v0.p, x, (size_t)n * 8));
+  LRN_TRY(prec_apply_dev(c, c->v0.as<double>(), c->v1.as<double>(), c->v2.as<double>()));
+  return copy_out(c, Mx, c->v1.p, (size_t)n * 8);
+}
+
+extern "C" int lrn_pcg(lrn_ctx* c, const double* h, double tol, int maxit, double* x, int* exit_code, int* iters) {
+  if (!c || !h || !x || !exit_code || !iters) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_TRY(copy_in(c, c->v0.p, h, (size_t)n * 8));
+  hipEvent_t a0, a1;
+  if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
+  LRN_TRY(pcg_dev(c, c->v0.as<double>(), tol, maxit, c->v3.as<double>(), exit_code, iters));
+  if (c->profile) {
+    (void)hipEventRecord(a1, c->stream); (void)hipEventSynchronize(a1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["pcg"] += ms; c->counts["pcg"] += 1; c->counts["pcg_iters"] += *iters;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+  }
+  return copy_out(c, x, c->v3.p, (size_t)n * 8);
+}

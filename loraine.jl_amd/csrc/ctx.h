@@ -5,6 +5,8 @@
 #include "chol.h"
 #include "lrn_common.h"
 
+namespace lrn { struct Prec; }
+
 struct LmiBlock {
   int msz = 0;
   long nent = 0;            // total stored entries (sparse lists)
@@ -22,6 +24,11 @@ struct LmiBlock {
   lrn::DBuf Adense;         // double [nd * msz^2], slot s = position s
   lrn::DBuf hidx;           // int32 [nvar] position -> row/col index of the Schur matrix
   lrn::DBuf sigma_d, ipos_d; // int32 [nvar] device copies of sigma / ipos
+  // stored columns of AA (sparse constraints only) for the deterministic AA'x gather
+  long ncq = 0;
+  lrn::DBuf cq_q, cq_ptr;   // int64 [ncq], [ncq+1]
+  lrn::DBuf cq_j;           // int32 constraint (natural index)
+  lrn::DBuf cq_v;           // double AA value
   // rank-one factors (datarank = -1): CSR by constraint (natural order)
   bool has_B = false;
   long bnnz = 0;
@@ -39,7 +46,8 @@ struct lrn_ctx {
   std::vector<LmiBlock> lmi;
   bool pos_space = false;       // Schur matrix kept in sigma-position space (nlmi == 1)
   // linear block C_lin (nvar x nlin) stored by linear constraint (CSC)
-  lrn::DBuf cl_ptr, cl_row, cl_val;   // int64 [nlin+1], int32, double
+  lrn::DBuf cl_ptr, cl_row, cl_val;   // int64 [nlin+1], int32 (Schur-matrix index), double
+  lrn::DBuf cl_rown;                  // int32 natural row index
   lrn::DBuf lin_xs;                   // X_lin .* S_lin_inv  [nlin]
   // Schur complement
   lrn::DBuf H;          // assembled (lower triangle authoritative), nvar x nvar
@@ -51,6 +59,7 @@ struct lrn_ctx {
   bool have_H = false, have_L = false;
   // assembly workspaces
   lrn::DBuf P, T, slabs, Hd, BG;
+  lrn::DBuf m0, m1, m2, cgbuf;   // msz^2 work matrices (mat-vec / rhs), PCG vectors
   long P_cap = 0, T_cap = 0;   // capacity in matrices
   // shard (multi-GPU): this rank assembles owner columns with (pos / shard_bs) % world == rank
   int rank = 0, world = 1, shard_bs = 128;
@@ -62,7 +71,7 @@ struct lrn_ctx {
   // generic scratch
   lrn::DBuf scratch;
   // preconditioner / CG state
-  struct Prec* prec = nullptr;
+  lrn::Prec* prec = nullptr;
 };
 
 namespace lrn {

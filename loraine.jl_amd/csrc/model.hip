@@ -145,7 +145,7 @@ __global__ void build_constraint_kernel(const long* __restrict__ ptr, const int*
 using namespace lrn;
 
 static void free_block(LmiBlock& b) {
-  for (DBuf* d : {&b.ent_ptr, &b.ent_r, &b.ent_c, &b.ent_v, &b.Adense, &b.hidx, &b.sigma_d, &b.ipos_d, &b.b_ptr, &b.b_col,
+  for (DBuf* d : {&b.ent_ptr, &b.ent_r, &b.ent_c, &b.ent_v, &b.Adense, &b.hidx, &b.sigma_d, &b.ipos_d, &b.cq_q, &b.cq_ptr, &b.cq_j, &b.cq_v, &b.b_ptr, &b.b_col,
                   &b.b_val, &b.X, &b.S, &b.W, &b.G, &b.Gi, &b.Si, &b.D, &b.DDsi})
     release(*d);
 }
@@ -154,7 +154,7 @@ void lrn_free_model(lrn_ctx* c) {
   for (auto& b : c->lmi) free_block(b);
   c->lmi.clear();
   for (DBuf* d : {&c->cl_ptr, &c->cl_row, &c->cl_val, &c->lin_xs, &c->H, &c->L, &c->Linv, &c->cholwork,
-                  &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->T, &c->slabs, &c->Hd, &c->BG})
+                  &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->T, &c->slabs, &c->Hd, &c->BG, &c->m0, &c->m1, &c->m2, &c->cgbuf, &c->cl_rown})
     release(*d);
   c->P_cap = c->T_cap = 0;
   c->have_H = c->have_L = false;
@@ -272,6 +272,31 @@ extern "C" int lrn_upload_model(lrn_ctx* c, int nlmi, int nvar, const int64_t* m
     }
     b.q_wave = b.nd;
     while (b.q_wave < b.npos_nz && b.nnz[b.q_wave] > 4) b.q_wave++;
+    {  // stored columns of AA restricted to the non-dense constraints
+      std::vector<long> cq_q, cq_ptr(1, 0);
+      std::vector<int> cq_j;
+      std::vector<double> cq_v;
+      for (long q = 0; q < ncol; ++q) {
+        long before = (long)cq_j.size();
+        for (long k = cp[q] - 1; k < cp[q + 1] - 1; ++k) {
+          if (nz[k] == 0.0) continue;
+          long j = rv[k] - 1;
+          if (b.ipos[j] < b.nd) continue;
+          cq_j.push_back((int)j);
+          cq_v.push_back(nz[k]);
+        }
+        if ((long)cq_j.size() > before) { cq_q.push_back(q); cq_ptr.push_back((long)cq_j.size()); }
+      }
+      b.ncq = (long)cq_q.size();
+      LRN_TRY(ensure(c, b.cq_q, (size_t)b.ncq * 8));
+      LRN_TRY(ensure(c, b.cq_ptr, (size_t)(b.ncq + 1) * 8));
+      LRN_TRY(ensure(c, b.cq_j, cq_j.size() * 4));
+      LRN_TRY(ensure(c, b.cq_v, cq_v.size() * 8));
+      LRN_TRY(copy_in(c, b.cq_q.p, cq_q.data(), (size_t)b.ncq * 8));
+      LRN_TRY(copy_in(c, b.cq_ptr.p, cq_ptr.data(), (size_t)(b.ncq + 1) * 8));
+      LRN_TRY(copy_in(c, b.cq_j.p, cq_j.data(), cq_j.size() * 4));
+      LRN_TRY(copy_in(c, b.cq_v.p, cq_v.data(), cq_v.size() * 8));
+    }
     LRN_TRY(ensure(c, b.ent_ptr, (size_t)(nvar + 1) * 8));
     LRN_TRY(ensure(c, b.ent_r, (size_t)b.nent * 4));
     LRN_TRY(ensure(c, b.ent_c, (size_t)b.nent * 4));
@@ -335,12 +360,15 @@ extern "C" int lrn_upload_model(lrn_ctx* c, int nlmi, int nvar, const int64_t* m
     long nn = Clin_colptr[nlin] - 1;
     std::vector<long> ptr(nlin + 1);
     for (int l = 0; l <= nlin; ++l) ptr[l] = Clin_colptr[l] - 1;
-    std::vector<int> row(nn);
+    std::vector<int> row(nn), rown(nn);
     for (long k = 0; k < nn; ++k) {
       long i = Clin_rowval[k] - 1;
       if (i < 0 || i >= nvar) return set_error(c, LRN_ERR_ARG, "C_lin rowval out of range");
       row[k] = c->pos_space ? c->lmi[0].ipos[i] : (int)i;
+      rown[k] = (int)i;
     }
+    LRN_TRY(ensure(c, c->cl_rown, (size_t)nn * 4));
+    LRN_TRY(copy_in(c, c->cl_rown.p, rown.data(), (size_t)nn * 4));
     LRN_TRY(ensure(c, c->cl_ptr, (size_t)(nlin + 1) * 8));
     LRN_TRY(ensure(c, c->cl_row, (size_t)nn * 4));
     LRN_TRY(ensure(c, c->cl_val, (size_t)nn * 8));

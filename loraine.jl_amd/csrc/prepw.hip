@@ -1,0 +1,211 @@
+// NT scaling on the device: prepare_W (reference src/prepare_W.jl:28-94).
+//   X = L_X L_X', S = L_S L_S'  (blocked Cholesky, chol.hip)        :33-34
+//   CC = L_S' L_X                 (MFMA GEMM)                        :39
+//   CC V = U diag(D)              (one-sided Jacobi SVD, jacobi.hip) :42
+//   G  = L_X V D^-1/2             (column scale + MFMA GEMM)         :60
+//   Gi = D^1/2 V' L_X^-1          (blocked TRSM instead of inv(G))   :63
+//   W  = G G'                     (MFMA GEMM, lower tiles + mirror)  :64
+//   Si = L_S^-T L_S^-1            (TRSM with I, then GEMM)           :68
+//   DDsi = 1/sqrt(diag(G' S G))   (GEMM S G + column dots)           :71-74
+#include "../../include/loraine_hip.h"
+#include "ctx.h"
+#include "jacobi.h"
+
+namespace lrn {
+
+__global__ void tril_kernel(double* __restrict__ A, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    if (i < j) A[e] = 0.0;
+  }
+}
+
+__global__ void eye_kernel(double* __restrict__ V, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    V[e] = (e % n == e / n) ? 1.0 : 0.0;
+}
+
+__global__ void mirror_lower_kernel(double* __restrict__ A, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    if (i < j) A[e] = A[(long)j + (long)i * n];
+  }
+}
+
+// B[:,j] = A[:,j] * f(d[j]);  mode 0: d^-1/2, 1: d^1/2
+__global__ void scale_cols_kernel(const double* __restrict__ A, const double* __restrict__ d, int n, int mode,
+                                  double* __restrict__ B) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int j = (int)(e / n);
+    double s = sqrt(d[j]);
+    B[e] = mode == 0 ? A[e] / s : A[e] * s;
+  }
+}
+
+__global__ void transpose_kernel(const double* __restrict__ A, int n, double* __restrict__ B) {
+  __shared__ double tile[32][33];
+  int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int i = bx + threadIdx.x, j = by + r;
+    if (i < n && j < n) tile[r][threadIdx.x] = A[(long)i + (long)j * n];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int i = by + threadIdx.x, j = bx + r;      // B[i][j] = A[j][i]
+    if (i < n && j < n) B[(long)i + (long)j * n] = tile[threadIdx.x][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void coldot_rsqrt_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                           int n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  const double* a = A + (long)blockIdx.x * n;
+  const double* b = B + (long)blockIdx.x * n;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += a[i] * b[i];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) sh[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = 1.0 / sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+static inline unsigned nb2(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+static int gemm_nn(hipStream_t st, int n, const double* A, bool tA, const double* B, bool tB, double* C, int flags = 0) {
+  GemmDesc g;
+  g.A = A; g.B = B; g.C = C;
+  g.M = g.N = g.K = n;
+  if (!tA) { g.sAm = 1; g.sAk = n; } else { g.sAm = n; g.sAk = 1; }
+  if (!tB) { g.sBk = 1; g.sBn = n; } else { g.sBk = n; g.sBn = 1; }
+  g.sCm = 1; g.sCn = n;
+  g.flags = flags;
+  return gemm(st, g);
+}
+
+int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
+  const int n = b.msz;
+  const size_t mm = (size_t)n * n * 8;
+  hipStream_t st = c->stream;
+  // workspace: LX, LS, CC/tmp, V, Y  (5 n^2) + Linv blocks x2 + chol work
+  size_t linv = chol_linv_doubles(n);
+  size_t need = (5 * (size_t)n * n + 2 * linv + (size_t)n * CHOL_NB + (size_t)CHOL_NB * n + 4 * (size_t)n) * 8;
+  LRN_TRY(ensure(c, c->scratch, need));
+  double* LX = c->scratch.as<double>();
+  double* LS = LX + (size_t)n * n;
+  double* CC = LS + (size_t)n * n;
+  double* V = CC + (size_t)n * n;
+  double* Y = V + (size_t)n * n;
+  double* LinvX = Y + (size_t)n * n;
+  double* LinvS = LinvX + linv;
+  double* cw = LinvS + linv;              // n*NB
+  double* tw = cw + (size_t)n * CHOL_NB;  // NB*n
+  int* dinfo = c->info_dev.as<int>();
+  *info = 0;
+  // Cholesky of X and S
+  LRN_HIP(c, hipMemcpyAsync(LX, b.X.p, mm, hipMemcpyDeviceToDevice, st));
+  LRN_HIP(c, hipMemsetAsync(dinfo, 0, 4, st));
+  LRN_TRY(potrf_lower(st, LX, n, n, LinvX, cw, dinfo));
+  int h = 0;
+  LRN_HIP(c, hipMemcpyAsync(&h, dinfo, 4, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipStreamSynchronize(st));
+  if (h != 0) { *info = 1; return LRN_OK; }
+  LRN_HIP(c, hipMemcpyAsync(LS, b.S.p, mm, hipMemcpyDeviceToDevice, st));
+  LRN_TRY(potrf_lower(st, LS, n, n, LinvS, cw, dinfo));
+  LRN_HIP(c, hipMemcpyAsync(&h, dinfo, 4, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipStreamSynchronize(st));
+  if (h != 0) { *info = 2; return LRN_OK; }
+  hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, LX, n);
+  hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, LS, n);
+  // CC = LS' LX ; SVD
+  tic(c);
+  LRN_TRY(gemm_nn(st, n, LS, true, LX, false, CC));
+  toc(c, "prepw_gemm");
+  tic(c);
+  int sweeps = 0;
+  LRN_TRY(jacobi_svd(c, CC, V, b.D.as<double>(), n, &sweeps));
+  c->counts["svd_sweeps"] = sweeps;
+  toc(c, "prepw_svd");
+  tic(c);
+  // G = LX (V D^-1/2)
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 0, CC);
+  LRN_TRY(gemm_nn(st, n, LX, false, CC, false, b.G.as<double>()));
+  // Gi' = LX^-T (V D^1/2)
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 1, Y);
+  LRN_TRY(trsm_left_lower(st, LX, n, n, LinvX, true, Y, n, n, tw));
+  hipLaunchKernelGGL(transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, st, Y, n, b.Gi.as<double>());
+  // W = G G'
+  LRN_TRY(gemm_nn(st, n, b.G.as<double>(), false, b.G.as<double>(), true, b.W.as<double>(), GEMM_TRI_LOWER));
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, b.W.as<double>(), n);
+  // Si = LS^-T LS^-1
+  hipLaunchKernelGGL(eye_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, Y, n);
+  LRN_TRY(trsm_left_lower(st, LS, n, n, LinvS, false, Y, n, n, tw));
+  LRN_TRY(gemm_nn(st, n, Y, true, Y, false, b.Si.as<double>(), GEMM_TRI_LOWER));
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, b.Si.as<double>(), n);
+  // DDsi = 1/sqrt(diag(G' S G))
+  LRN_TRY(gemm_nn(st, n, b.S.as<double>(), false, b.G.as<double>(), false, CC));
+  hipLaunchKernelGGL(coldot_rsqrt_kernel, dim3(n), dim3(256), 0, st, b.G.as<double>(), CC, n, b.DDsi.as<double>());
+  toc(c, "prepw_gemm");
+  LRN_HIP(c, hipGetLastError());
+  b.have_W = b.have_G = true;
+  return LRN_OK;
+}
+
+}  // namespace lrn
+
+using namespace lrn;
+
+extern "C" int lrn_prepare_w(lrn_ctx* c, int il, const double* X, const double* S, double* D, double* G,
+                             double* Gi, double* W, double* Si, double* DDsi, int* info) {
+  if (!c || il < 0 || il >= c->nlmi || !X || !S || !info) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  LmiBlock& b = c->lmi[il];
+  const size_t mm = (size_t)b.msz * b.msz * 8, mv = (size_t)b.msz * 8;
+  LRN_TRY(copy_in(c, b.X.p, X, mm));
+  LRN_TRY(copy_in(c, b.S.p, S, mm));
+  hipEvent_t a0, a1;
+  if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
+  LRN_TRY(prepare_w_block(c, b, info));
+  if (c->profile) {
+    (void)hipEventRecord(a1, c->stream); (void)hipEventSynchronize(a1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["prepare_w"] += ms; c->counts["prepare_w"] += 1;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+  }
+  if (*info != 0) return LRN_OK;
+  if (D) LRN_TRY(copy_out(c, D, b.D.p, mv));
+  if (G) LRN_TRY(copy_out(c, G, b.G.p, mm));
+  if (Gi) LRN_TRY(copy_out(c, Gi, b.Gi.p, mm));
+  if (W) LRN_TRY(copy_out(c, W, b.W.p, mm));
+  if (Si) LRN_TRY(copy_out(c, Si, b.Si.p, mm));
+  if (DDsi) LRN_TRY(copy_out(c, DDsi, b.DDsi.p, mv));
+  return LRN_OK;
+}
+
+extern "C" int lrn_dbg_svd_jacobi(lrn_ctx* c, int n, const double* A, double* U_sigma, double* V, double* sigma,
+                                  int* sweeps) {
+  if (!c || n <= 0 || !A || !U_sigma || !V || !sigma) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf dA, dV, dS;
+  size_t mm = (size_t)n * n * 8;
+  LRN_TRY(ensure(c, dA, mm));
+  LRN_TRY(ensure(c, dV, mm));
+  LRN_TRY(ensure(c, dS, (size_t)n * 8));
+  LRN_TRY(copy_in(c, dA.p, A, mm));
+  int sw = 0;
+  LRN_TRY(jacobi_svd(c, dA.as<double>(), dV.as<double>(), dS.as<double>(), n, &sw));
+  if (sweeps) *sweeps = sw;
+  LRN_TRY(copy_out(c, U_sigma, dA.p, mm));
+  LRN_TRY(copy_out(c, V, dV.p, mm));
+  int rc = copy_out(c, sigma, dS.p, (size_t)n * 8);
+  release(dA); release(dV); release(dS);
+  return rc;
+}

@@ -88,7 +88,7 @@ def test_gemm_packed_symmetric_dot(dev):
     Amat = np.asfortranarray(As.transpose(0, 2, 1).reshape(nv, m * m).T)     # (m^2 x nv), col-major vec
     Tmat = np.asfortranarray(T_st.transpose(0, 2, 1).reshape(nv, m * m).T)
     H = dev.dbg_gemm(Amat, Tmat, True, False, flags=_capi.GEMM_TRI_LOWER | _capi.GEMM_KSEG_TRI, ksplit=3)
-    Href = np.einsum("iab,jab->ij", As, Tfull)
+    Href = As.reshape(nv, -1) @ Tfull.reshape(nv, -1).T
     t2 = np.arange(nv) // 128
     mask = t2[:, None] >= t2[None, :]
     assert relerr(H[mask], Href[mask]) < 1e-13

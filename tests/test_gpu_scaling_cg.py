@@ -1,0 +1,173 @@
+"""GPU parity: NT scaling (prepare_W), Jacobi SVD, CG operator, preconditioners and PCG
+through the C ABI against the CPU oracle (reference src/prepare_W.jl, src/Solvers.jl:572-904)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import loraine_oracle as lo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import loraine_jl_amd
+    d = loraine_jl_amd.Device(0)
+    yield d
+    d.close()
+
+
+def relerr(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _spd(m, seed, cond=1e4):
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    lam = np.logspace(0, np.log10(cond), m)
+    return (Q * lam[None, :]) @ Q.T
+
+
+@pytest.mark.parametrize("n", [5, 50, 96, 97, 300])
+def test_jacobi_svd(dev, n):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)) @ np.diag(np.logspace(0, -6, n)) @ rng.standard_normal((n, n))
+    US, s, V, sweeps = dev.dbg_svd_jacobi(A)
+    assert 0 < sweeps < 40
+    assert relerr(A @ V, US) < 1e-12
+    assert np.linalg.norm(V.T @ V - np.eye(n)) < 1e-12 * n
+    sref = np.linalg.svd(A, compute_uv=False)
+    assert np.allclose(np.sort(s)[::-1], sref, rtol=1e-10, atol=1e-14 * sref[0])
+    U = US / s[None, :]
+    assert np.linalg.norm(U.T @ U - np.eye(n)) < 1e-9 * n
+
+
+@pytest.mark.parametrize("m,cond", [(10, 1e2), (50, 1e4), (130, 1e6), (400, 1e8)])
+def test_prepare_w_matches_oracle_and_identities(dev, m, cond):
+    X = _spd(m, 1, cond)
+    S = _spd(m, 2, cond)
+    # a one-block model just to size the context
+    import scipy.sparse as sp
+    A = [[sp.csc_matrix((m, m)), sp.identity(m, format="csc")]]
+    model = lo.make_model(A, np.ones(1), 0.0, None, None)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    info, out = dev.prepare_w(0, X, S)
+    assert info == 0
+    sol = types.SimpleNamespace(model=model, X=[X.copy()], S=[S.copy()], D=[None], G=[None], Gi=[None], W=[None],
+                                Si=[None], DDsi=[None], S_lin=np.zeros(0), status=0)
+    lo.prepare_W(sol)
+    tol = 1e-14 * cond * m
+    assert np.allclose(np.sort(out["D"]), np.sort(sol.D[0]), rtol=1e-10)
+    assert relerr(out["W"], sol.W[0]) < tol                       # W is unique
+    assert relerr(out["Si"], sol.Si[0]) < tol
+    G, Gi, W, D = out["G"], out["Gi"], out["W"], out["D"]
+    # identities: W S W = X, G'SG = Gi X Gi' = diag(D), Gi = inv(G)
+    assert relerr(W @ S @ W, X) < tol
+    assert relerr(G.T @ S @ G, np.diag(D)) < tol
+    assert relerr(Gi @ X @ Gi.T, np.diag(D)) < tol
+    assert relerr(G @ Gi, np.eye(m)) < tol
+    assert np.array_equal(W, W.T)
+    assert np.allclose(np.sort(out["DDsi"]), np.sort(sol.DDsi[0]), rtol=1e-8)
+
+
+def test_prepare_w_reports_not_pd(dev):
+    import scipy.sparse as sp
+    m = 20
+    A = [[sp.csc_matrix((m, m)), sp.identity(m, format="csc")]]
+    model = lo.make_model(A, np.ones(1), 0.0, None, None)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    X = _spd(m, 1); S = _spd(m, 2)
+    Xb = X.copy(); Xb[3, 3] = -1.0
+    assert dev.prepare_w(0, Xb, S)[0] == 1
+    Sb = S.copy(); Sb[7, 7] = -1.0
+    assert dev.prepare_w(0, X, Sb)[0] == 2
+
+
+def _iterate(model, kit_opts, iters=3):
+    """run a few oracle IP iterations to get a realistic (X, S, W, G) iterate"""
+    s = lo.MySolver(model, dict(kit_opts, verb=0, maxit=iters))
+    lo.solve(s)
+    return s
+
+
+@pytest.mark.parametrize("name", ["theta1", "control1", "tru3"])
+def test_matvec_equals_H_times_x(dev, name):
+    model = lo.model_from_sdpa(os.path.join(GOLD, f"{name}.dat-s"))
+    s = _iterate(model, dict(kit=0), 4)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes, C_lin=model.C_lin if model.nlin else None)
+    for i in range(model.nlmi):
+        dev.set_scaling(i, s.W[i], s.G[i])
+    if model.nlin:
+        dev.set_lin(s.X_lin, s.S_lin_inv)
+    H = dev.schur_assemble(0, want_H=True)
+    x = np.random.default_rng(0).standard_normal(model.n)
+    y = dev.matvec(x)
+    assert relerr(y, H @ x) < 1e-12
+    # against the oracle operator (Solvers.jl:582-614)
+    yo = np.zeros(model.n)
+    lo.MyA(s.W, model.AA, model.nlin, model.C_lin, s.X_lin, s.S_lin_inv)(yo, x)
+    assert relerr(y, yo) < 1e-12
+
+
+def test_make_rhs_matches_oracle(dev):
+    model = lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
+    s = _iterate(model, dict(kit=0), 3)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    dev.set_scaling(0, s.W[0], s.G[0])
+    h = dev.make_rhs(s.Rp, [s.Rd[0] + s.S[0]])
+    href = lo.makeRHS(1, model.AA, s.W, s.S, s.Rp, s.Rd)
+    assert relerr(h, href) < 1e-12
+
+
+@pytest.mark.parametrize("prec,erank", [(0, 1), (2, 1), (1, 1), (1, 3)])
+def test_preconditioner_apply_and_pcg(dev, prec, erank):
+    model = lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
+    s = _iterate(model, dict(kit=1, preconditioner=max(prec, 1) if prec else 0, erank=erank), 6)
+    X, S = s.X[0], s.S[0]
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    info, out = dev.prepare_w(0, X, S)
+    assert info == 0
+    # oracle state with the device's scaling (W is unique; G is not -> use the device's)
+    s.W[0], s.G[0] = out["W"], out["G"]
+    s.preconditioner, s.erank = prec, erank
+    ha = lo.Halpha(1)
+    if prec == 1:
+        lo.Prec_for_CG_tilS_prep(s, ha)
+        Mo = lo.MyM(model.AA, ha.AAAATtau, ha.Umat, ha.Z, ha.cholS)
+    elif prec == 2:
+        lo.Prec_for_CG_beta(s, ha)
+        Mo = lo.MyM_beta(model.AA, ha.AAAATtau)
+    else:
+        Mo = lo.MyM_no()
+    assert dev.prec_setup(prec, erank, s.aamat) == 0
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(model.n)
+    ref = np.zeros(model.n)
+    Mo(ref, x)
+    got = dev.prec_apply(x)
+    assert relerr(got, ref) < 1e-9
+    # PCG against the oracle's cg on the same operator
+    h = rng.standard_normal(model.n)
+    Ao = lo.MyA(s.W, model.AA, 0, model.C_lin, s.X_lin, s.S_lin_inv)
+    xr, ec_r, it_r = lo.cg(Ao, h, tol=1e-8, maxIter=10000, precon=Mo)
+    xg, ec_g, it_g = dev.pcg(h, 1e-8, 10000)
+    assert ec_g == ec_r == 30
+    assert abs(it_g - it_r) <= max(2, it_r // 10)
+    assert relerr(xg, xr) < 1e-6
+    res = np.zeros(model.n); Ao(res, xg)
+    assert np.linalg.norm(res - h) / np.linalg.norm(h) < 2e-8
+
+
+def test_pcg_trivial_exits(dev):
+    model = lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
+    s = _iterate(model, dict(kit=0), 2)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    dev.set_scaling(0, s.W[0], s.G[0])
+    dev.prec_setup(0, 1, 1)
+    x, ec, it = dev.pcg(np.zeros(model.n), 1e-6)
+    assert (ec, it) == (1, 0) and not x.any()
+    x, ec, it = dev.pcg(1e-9 * np.ones(model.n), 1e-6)
+    assert (ec, it) == (2, 0)

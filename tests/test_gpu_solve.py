@@ -1,0 +1,82 @@
+"""GPU end-to-end: the host driver (loraine.jl_amd/solvers.py) with the hot path on MI355X
+against the reference's known answers and against the CPU oracle's trajectory."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import loraine_oracle as lo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _run(path, **opts):
+    from loraine_jl_amd.optimizer import Optimizer
+    o = Optimizer()
+    o.set_silent(True)
+    for k, v in opts.items():
+        o.set_attribute(k, v)
+    o.read_from_file(path)
+    o.optimize()
+    return o
+
+
+def test_theta1_kit0_known_answer_and_oracle_parity():
+    # examples/solve_sdpa.jl:43-61
+    opts = dict(kit=0, eDIMACS=1e-6, initpoint=1, aamat=2, datasparsity=8)
+    o = _run(os.path.join(GOLD, "theta1.dat-s"), **opts)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(23.0, rel=1e-6)
+    ref = lo.MySolver(lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s")), dict(opts, verb=0))
+    lo.solve(ref)
+    assert o.solver.iter == ref.iter
+    # north-star parity: objectives and DIMACS errors within 1e-8 relative of the CPU path
+    assert o.objective_value() == pytest.approx(lo.objective_value(ref), rel=1e-8)
+    assert o.dual_objective_value() == pytest.approx(lo.dual_objective_value(ref), rel=1e-8)
+    for tg, tr in zip(o.solver.trace, ref.trace):
+        assert tg["primal_obj"] == pytest.approx(tr["primal_obj"], rel=1e-8, abs=1e-10)
+        assert tg["dimacs"] == pytest.approx(tr["dimacs"], rel=1e-4, abs=1e-10)
+
+
+def test_unknown_option_rejected():
+    from loraine_jl_amd.optimizer import Optimizer, UnsupportedAttribute
+    o = Optimizer()
+    with pytest.raises(UnsupportedAttribute):
+        o.set_attribute("no_such_option", 1)
+    assert o.get_attribute("eDIMACS") == 1e-7 and o.get_attribute("maxit") == 100
+
+
+@pytest.mark.parametrize("name,opt", [("control1", 17.78463), ("tru3", None), ("vib3", None)])
+def test_multi_block_and_linear_rows(name, opt):
+    path = os.path.join(GOLD, f"{name}.dat-s")
+    o = _run(path, kit=0)
+    assert o.termination_status() == "OPTIMAL"
+    ref = lo.MySolver(lo.model_from_sdpa(path), dict(kit=0, verb=0))
+    lo.solve(ref)
+    assert o.objective_value() == pytest.approx(lo.objective_value(ref), rel=1e-7, abs=1e-9)
+    if opt is not None:
+        assert o.objective_value() == pytest.approx(opt, rel=1e-6)
+
+
+def test_maxG11_rank1_known_optimum():
+    # BASELINE config 2: kit=0, datarank=-1 ; SDPLIB optimum 629.1648 (external)
+    o = _run(os.path.join(GOLD, "maxG11.dat-s"), kit=0, datarank=-1)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(629.1648, rel=1e-6)
+    assert o.objective_value() == pytest.approx(o.dual_objective_value(), rel=1e-6)
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2, 4])
+def test_theta1_kit1_all_preconditioners(prec):
+    o = _run(os.path.join(GOLD, "theta1.dat-s"), kit=1, preconditioner=prec, eDIMACS=1e-6, initpoint=1)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(23.0, rel=1e-5)
+    assert o.solver.cg_iter_tot > 0
+
+
+def test_thetaG11_pcg_halpha():
+    # BASELINE config 3: kit=1, preconditioner=1, erank=1 ; SDPLIB optimum 400.00 (external)
+    o = _run(os.path.join(GOLD, "thetaG11.dat-s"), kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(400.0, rel=1e-4)
