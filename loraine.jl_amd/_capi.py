@@ -76,6 +76,12 @@ def load_library():
         raise LoraineHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime; load it FIRST so that this library and
+        # torch (device tensors, torch.distributed/RCCL) share one runtime in the process.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

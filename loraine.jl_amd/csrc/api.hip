@@ -160,7 +160,7 @@ int lrn_schur_export_shard(lrn_ctx* c, double* buf) {
   shard_geom(c, &nblk, &bpr);
   const long n = c->nvar, bs = c->shard_bs;
   for (int lb = 0; lb < bpr; ++lb) {
-    int gb = lb * c->world + c->rank;
+    int gb = shard_global_block(c->rank, lb, c->world);
     double* dst = buf + (long)lb * bs * n;
     if (gb >= nblk) {
       LRN_HIP(c, hipMemsetAsync(dst, 0, (size_t)bs * n * 8, c->stream));
@@ -183,7 +183,7 @@ int lrn_schur_import_all(lrn_ctx* c, const double* buf_all) {
   const long per_rank = (long)bpr * bs * n;
   for (int r = 0; r < c->world; ++r)
     for (int lb = 0; lb < bpr; ++lb) {
-      int gb = lb * c->world + r;
+      int gb = shard_global_block(r, lb, c->world);
       if (gb >= nblk) continue;
       long c0 = (long)gb * bs, nc = std::min<long>(bs, n - c0);
       LRN_HIP(c, hipMemcpyAsync(c->H.as<double>() + c0 * n, buf_all + (long)r * per_rank + (long)lb * bs * n,

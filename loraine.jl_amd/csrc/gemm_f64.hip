@@ -355,16 +355,14 @@ int mfma_f64_probe(hipStream_t st, const double* A, const double* B, double* D) 
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
   v4f64 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
   double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  // inline asm keeps the accumulators in VGPRs (the builtin form made hipcc shuttle them
+  // through AGPRs every iteration, which measured the copies, not the matrix pipe)
+#define LRN_MFMA(c) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
   for (int i = 0; i < iters; ++i) {
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-    c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
-    c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c4, 0, 0, 0);
-    c5 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c5, 0, 0, 0);
-    c6 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c6, 0, 0, 0);
-    c7 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c7, 0, 0, 0);
+    LRN_MFMA(c0); LRN_MFMA(c1); LRN_MFMA(c2); LRN_MFMA(c3);
+    LRN_MFMA(c4); LRN_MFMA(c5); LRN_MFMA(c6); LRN_MFMA(c7);
   }
+#undef LRN_MFMA
   v4f64 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
   if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];
 }

@@ -19,6 +19,17 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace lrn {
 
+// Multi-GPU ownership of Schur column block `blk`: snake (boustrophedon) block-cyclic, so the
+// triangular work (long columns first) is balanced across ranks.
+__host__ __device__ inline int shard_owner(int blk, int world) {
+  int r = blk % world;
+  return ((blk / world) & 1) ? world - 1 - r : r;
+}
+// global block of (rank, local block lb)
+__host__ __device__ inline int shard_global_block(int rank, int lb, int world) {
+  return lb * world + ((lb & 1) ? world - 1 - rank : rank);
+}
+
 // ---------------------------------------------------------------- device buffer
 struct DBuf {
   void* p = nullptr;

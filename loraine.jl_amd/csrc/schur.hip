@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void pair_wave_kernel(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int pi = p_lo + blockIdx.y;
   if (pi >= p_hi) return;
-  if (world > 1 && (pi / bs) % world != rank) return;
+  if (world > 1 && shard_owner(pi / bs, world) != rank) return;
   const int pj = pi + blockIdx.x * 4 + wv;
   if (pj >= p_end) return;
   const long ib = ptr[pi], jb = ptr[pj];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void pair_thread_kernel(
     const int* __restrict__ hidx, double* __restrict__ H, int ldh, int rank, int world, int bs) {
   const int pi = p_lo + blockIdx.y;
   if (pi >= p_end) return;
-  if (world > 1 && (pi / bs) % world != rank) return;
+  if (world > 1 && shard_owner(pi / bs, world) != rank) return;
   const int pj = pi + blockIdx.x * 256 + threadIdx.x;
   if (pj >= p_end) return;
   const long ib = ptr[pi], jb = ptr[pj];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void lin_schur_kernel(const long* __restrict__
     int i = idx / n, j = idx - i * n;
     int ri = row[b + i], rj = row[b + j];
     if (ri < rj) continue;
-    if (world > 1 && (rj / bs) % world != rank) continue;
+    if (world > 1 && shard_owner(rj / bs, world) != rank) continue;
     atomicAdd(&H[(long)ri + (long)rj * ldh], val[b + i] * val[b + j] * d);
   }
 }
@@ -251,7 +251,7 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   std::vector<std::pair<int, int>> groups;
   if (c->world > 1) {
     for (int s0 = 0; s0 < nd; s0 += c->shard_bs)
-      if ((s0 / c->shard_bs) % c->world == c->rank) {
+      if (shard_owner(s0 / c->shard_bs, c->world) == c->rank) {
         int s1 = std::min(nd, s0 + c->shard_bs);
         for (int a = s0; a < s1; a += (int)c->T_cap) groups.push_back({a, std::min(s1, a + (int)c->T_cap)});
       }

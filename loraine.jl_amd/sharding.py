@@ -1,0 +1,89 @@
+"""Multi-GPU layout of the Schur complement (kit=0): one process per GPU, every rank holds the
+full static data, assembles the lower-triangle COLUMN BLOCKS it owns (block-cyclic in the
+reference's nnz-sorted order, so the triangular work is balanced), and one RCCL all-gather
+over xGMI gives every rank the whole matrix before the (replicated) Cholesky.
+
+The exchange buffers are rank-major: rank r's buffer holds its blocks (snake block-cyclic: r, 2P-1-r, 2P+r, ...) each
+`bs` columns x nvar rows, zero-padded to `blocks_per_rank` so that all ranks send the same
+number of bytes (all_gather_into_tensor needs equal sizes).  The C library implements the
+same layout (lrn_schur_export_shard / lrn_schur_import_all); the pure-Python pack/unpack here
+are the executable specification used by the CPU (gloo) tests.
+"""
+import numpy as np
+
+SHARD_BS = 128
+
+
+def geometry(nvar, world, bs=SHARD_BS):
+    nblk = (nvar + bs - 1) // bs
+    bpr = (nblk + world - 1) // world
+    return nblk, bpr, bpr * bs * nvar
+
+
+def owner_of_block(blk, world):
+    """snake (boustrophedon) block-cyclic: rounds alternate direction so that the long
+    (early) columns of the lower triangle are spread evenly -- same map as shard_owner()
+    in csrc/lrn_common.h."""
+    r = blk % world
+    return world - 1 - r if (blk // world) & 1 else r
+
+
+def global_block(rank, lb, world):
+    return lb * world + (world - 1 - rank if lb & 1 else rank)
+
+
+def owner_of_column(col, world, bs=SHARD_BS):
+    return owner_of_block(col // bs, world)
+
+
+def owned_columns(nvar, rank, world, bs=SHARD_BS):
+    return [c for c in range(nvar) if owner_of_column(c, world, bs) == rank]
+
+
+def pack_shard(H, rank, world, bs=SHARD_BS):
+    """H: (nvar x nvar) column-major-addressable array -> flat shard buffer of this rank."""
+    nvar = H.shape[0]
+    nblk, bpr, size = geometry(nvar, world, bs)
+    buf = np.zeros(size)
+    for lb in range(bpr):
+        gb = global_block(rank, lb, world)
+        if gb >= nblk:
+            continue
+        c0, c1 = gb * bs, min(nvar, (gb + 1) * bs)
+        buf[lb * bs * nvar: lb * bs * nvar + (c1 - c0) * nvar] = np.asarray(H[:, c0:c1]).reshape(-1, order="F")
+    return buf
+
+
+def unpack_all(buf_all, nvar, world, bs=SHARD_BS):
+    """Inverse of the all-gather of `pack_shard` buffers -> (nvar x nvar) matrix."""
+    nblk, bpr, size = geometry(nvar, world, bs)
+    H = np.zeros((nvar, nvar), order="F")
+    for r in range(world):
+        for lb in range(bpr):
+            gb = global_block(r, lb, world)
+            if gb >= nblk:
+                continue
+            c0, c1 = gb * bs, min(nvar, (gb + 1) * bs)
+            seg = buf_all[r * size + lb * bs * nvar: r * size + lb * bs * nvar + (c1 - c0) * nvar]
+            H[:, c0:c1] = np.asarray(seg).reshape(nvar, c1 - c0, order="F")
+    return H
+
+
+class SchurExchange:
+    """The collective step of the sharded direct solve (product path, GPU tensors)."""
+
+    def __init__(self, dev, rank, world, group=None):
+        import torch
+        self.dev, self.rank, self.world, self.group = dev, rank, world, group
+        dev.set_shard(rank, world)
+        n = dev.shard_doubles()
+        self.shard = torch.zeros(n, dtype=torch.float64, device="cuda")
+        self.gathered = torch.zeros(n * world, dtype=torch.float64, device="cuda")
+
+    def allgather(self):
+        import torch
+        import torch.distributed as dist
+        self.dev.schur_export_shard(self.shard)
+        dist.all_gather_into_tensor(self.gathered, self.shard, group=self.group)    # RCCL over xGMI
+        torch.cuda.current_stream().synchronize()
+        self.dev.schur_import_all(self.gathered)
