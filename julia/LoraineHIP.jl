@@ -1,0 +1,160 @@
+# LoraineHIP.jl -- Julia-side glue that binds libloraine_hip.so (include/loraine_hip.h) behind
+# the reference's own function names, so `Loraine.Solvers.predictor/corrector` run unchanged.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia toolchain (SURVEY.md
+# section 0, fact 5).  This is the binding a Loraine.jl maintainer adds; the Python host in
+# `loraine.jl_amd/solvers.py` drives exactly the same C entry points and is what the parity
+# tests and the benchmark run.  See INTEGRATION.md.
+#
+# Usage (inside Loraine.jl, after `include("Solvers.jl")`):
+#     include("LoraineHIP.jl"); LoraineHIP.enable!(solver)     # once per `load`
+module LoraineHIP
+
+using SparseArrays, LinearAlgebra
+
+const LIB = get(ENV, "LORAINE_HIP_LIB", joinpath(@__DIR__, "..", "loraine.jl_amd", "libloraine_hip.so"))
+
+mutable struct Ctx
+    h::Ptr{Cvoid}
+end
+
+function check(ctx::Ctx, rc::Cint, what)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:lrn_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx.h))
+    error("$what failed ($rc): $msg")
+end
+
+function Ctx(device::Integer = 0)
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:lrn_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), r, device)
+    rc == 0 || error("lrn_create failed ($rc): no MI355X visible? (there is no CPU fallback)")
+    ctx = Ctx(r[])
+    finalizer(c -> ccall((:lrn_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), ctx)
+    return ctx
+end
+
+# ---- static data: MyModel (src/model.jl:34-87) -> device, once per `load` -------------------
+function upload_model!(ctx::Ctx, model)
+    nlmi, n = model.nlmi, model.n
+    colptr = [Vector{Int64}(model.AA[i].colptr) for i in 1:nlmi]     # SparseMatrixCSC is already
+    rowval = [Vector{Int64}(model.AA[i].rowval) for i in 1:nlmi]     # (colptr,rowval,nzval) 1-based
+    nzval = [Vector{Float64}(model.AA[i].nzval) for i in 1:nlmi]
+    hasB = !isempty(model.B)
+    bcol = hasB ? [Vector{Int64}(model.B[i].colptr) for i in 1:nlmi] : Vector{Int64}[]
+    brow = hasB ? [Vector{Int64}(model.B[i].rowval) for i in 1:nlmi] : Vector{Int64}[]
+    bval = hasB ? [Vector{Float64}(model.B[i].nzval) for i in 1:nlmi] : Vector{Float64}[]
+    p(v) = isempty(v) ? C_NULL : pointer(map(pointer, v))
+    cl = model.C_lin
+    GC.@preserve colptr rowval nzval bcol brow bval begin
+        rc = ccall((:lrn_upload_model, LIB), Cint,
+            (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}},
+             Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64},
+             Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}),
+            ctx.h, nlmi, n, Vector{Int64}(model.msizes), p(colptr), p(rowval), p(nzval),
+            p(bcol), p(brow), p(bval), Matrix{Int64}(model.sigmaA), Matrix{Int64}(model.qA),
+            model.nlin, Vector{Int64}(cl.colptr), Vector{Int64}(cl.rowval), Vector{Float64}(cl.nzval))
+    end
+    check(ctx, rc, "lrn_upload_model")
+end
+
+# ---- prepare_W (src/prepare_W.jl:28-94) -------------------------------------------------------
+function prepare_W(ctx::Ctx, solver)
+    for i in 1:solver.model.nlmi
+        m = solver.model.msizes[i]
+        tries = 0
+        while true
+            info = Ref{Cint}(0)
+            rc = ccall((:lrn_prepare_w, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Cint}),
+                ctx.h, i - 1, solver.X[i], solver.S[i], solver.D[i], solver.G[i], solver.Gi[i],
+                solver.W[i], solver.Si[i], solver.DDsi[i], info)
+            check(ctx, rc, "lrn_prepare_w")
+            info[] == 0 && break
+            # try_cholesky's regularisation loop (prepare_W.jl:12-24), replayed from `info`
+            M = info[] == 1 ? solver.X : solver.S
+            M[i] += 1e-5 .* I(m)
+            tries += 1
+            if tries > 1000
+                solver.status = 4
+                return
+            end
+        end
+    end
+    solver.Si_lin = solver.model.nlin > 0 ? 1.0 ./ solver.S_lin : []
+    return solver.D, solver.G, solver.Gi, solver.W, solver.Si, solver.DDsi, solver.Si_lin
+end
+
+# ---- makeBBBBs / makeBBBB_rank1 (src/makeBBBB.jl) + cholesky + solves ------------------------
+function makeBBBB!(ctx::Ctx, solver; want_matrix::Bool = false)
+    if solver.model.nlin > 0
+        check(ctx, ccall((:lrn_set_lin, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+            ctx.h, vec(solver.X_lin), vec(solver.S_lin_inv)), "lrn_set_lin")
+    end
+    mode = solver.datarank == -1 ? -1 : 0
+    H = want_matrix ? Matrix{Float64}(undef, solver.model.n, solver.model.n) : nothing
+    check(ctx, ccall((:lrn_schur_assemble, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}),
+        ctx.h, mode, want_matrix ? H : C_NULL), "lrn_schur_assemble")
+    return H
+end
+
+function factor!(ctx::Ctx, solver)          # predictor_corrector.jl:55-85
+    info = Ref{Cint}(0)
+    check(ctx, ccall((:lrn_schur_factor, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), ctx.h, info), "lrn_schur_factor")
+    info[] == 0 && return true
+    solver.regcount += 1
+    solver.regcount > 5 && (solver.status = 3; return false)
+    for _ in 1:1001
+        check(ctx, ccall((:lrn_schur_add_diag, LIB), Cint, (Ptr{Cvoid}, Cdouble), ctx.h, 1e-4), "lrn_schur_add_diag")
+        check(ctx, ccall((:lrn_schur_factor, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), ctx.h, info), "lrn_schur_factor")
+        info[] == 0 && return true
+    end
+    solver.status = 3
+    return false
+end
+
+function solve(ctx::Ctx, h::Vector{Float64})   # L' \ (L \ h)
+    x = similar(h)
+    check(ctx, ccall((:lrn_schur_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, h, x), "lrn_schur_solve")
+    return x
+end
+
+function makeRHS(ctx::Ctx, solver)             # makeBBBB.jl:221-228
+    mats = [solver.Rd[i] + solver.S[i] for i in 1:solver.model.nlmi]
+    h = Vector{Float64}(undef, solver.model.n)
+    GC.@preserve mats begin
+        ptrs = map(pointer, mats)
+        check(ctx, ccall((:lrn_make_rhs, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Ptr{Float64}}, Ptr{Float64}),
+            ctx.h, vec(solver.Rp), ptrs, h), "lrn_make_rhs")
+    end
+    return h
+end
+
+# ---- operator protocol consumed by cg (Solvers.jl:582,620,670,866) ---------------------------
+struct MyA_hip;  ctx::Ctx; end
+struct MyM_hip;  ctx::Ctx; end
+function (t::MyA_hip)(Ax::Vector{Float64}, x::Vector{Float64})
+    check(t.ctx, ccall((:lrn_matvec, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), t.ctx.h, x, Ax), "lrn_matvec")
+end
+function (t::MyM_hip)(Mx::Vector{Float64}, x::Vector{Float64})
+    check(t.ctx, ccall((:lrn_prec_apply, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), t.ctx.h, x, Mx), "lrn_prec_apply")
+end
+
+# Prec_for_CG_tilS_prep (prec = 1) / Prec_for_CG_beta (prec = 2 or 4) / none (0)
+function prec_setup!(ctx::Ctx, solver)
+    kind = solver.preconditioner == 1 ? 1 : (solver.preconditioner in (2, 4) ? 2 : 0)
+    info = Ref{Cint}(0)
+    check(ctx, ccall((:lrn_prec_setup, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Cint}),
+        ctx.h, kind, solver.erank, solver.aamat, info), "lrn_prec_setup")
+    info[] == 0 || throw(PosDefException(info[]))
+end
+
+# whole PCG on the device: replaces cg(A, h; tol, maxIter, precon) at predictor_corrector.jl:134,235
+function cg(ctx::Ctx, h::Vector{Float64}; tol::Float64, maxIter::Int = 10000)
+    x = similar(h); ec = Ref{Cint}(0); it = Ref{Cint}(0)
+    check(ctx, ccall((:lrn_pcg, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cdouble, Cint, Ptr{Float64}, Ref{Cint}, Ref{Cint}),
+        ctx.h, h, tol, maxIter, x, ec, it), "lrn_pcg")
+    return x, Int(ec[]), Int(it[])
+end
+
+end # module

@@ -44,7 +44,7 @@ __device__ __forceinline__ int lds_idx(int m, int k) {
   return KC ? (m * (BK + 2) + k) : (k * (BM + 16) + m);
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool KSEG>
+template <int BM, int BN, bool AKC, bool BKC, bool KSEG, bool EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   constexpr int TM = BM / 32, TN = BN / 32;       // MFMA tiles per wave
   constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   }
 
   // ---- epilogue
-  const bool x2 = (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
+  const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
   const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
-  const bool sq = d.flags & GEMM_SQUARE;
+  const bool sq = EPI && (d.flags & GEMM_SQUARE);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -209,12 +209,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
       }
 }
 
-template <int BM, int BN, bool KSEG>
+template <int BM, int BN, bool KSEG, bool EPI>
 static void launch4(hipStream_t st, const GemmParams& p, bool akc, bool bkc, dim3 grid) {
-  if (akc && bkc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, KSEG>), grid, dim3(256), 0, st, p);
-  else if (akc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, KSEG>), grid, dim3(256), 0, st, p);
-  else if (bkc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, KSEG>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, KSEG>), grid, dim3(256), 0, st, p);
+  if (akc && bkc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, KSEG, EPI>), grid, dim3(256), 0, st, p);
+  else if (akc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, KSEG, EPI>), grid, dim3(256), 0, st, p);
+  else if (bkc) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, KSEG, EPI>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, KSEG, EPI>), grid, dim3(256), 0, st, p);
 }
 
 // (tm, tn) enumeration: 8x8 super-tiles (tm fastest inside), only the tiles a TRI flag keeps.
@@ -305,12 +305,15 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   const bool bkc = (d.sBk == 1 && d.sBn != 1);
   dim3 grid(ntile, 1, d.batch * d.ksplit);
   if (grid.z > 65535) return LRN_ERR_ARG;
+  const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE);
   if (small) {
-    if (kseg) launch4<64, 64, true>(st, p, akc, bkc, grid);
-    else launch4<64, 64, false>(st, p, akc, bkc, grid);
+    if (kseg) launch4<64, 64, true, false>(st, p, akc, bkc, grid);
+    else if (epi) launch4<64, 64, false, true>(st, p, akc, bkc, grid);
+    else launch4<64, 64, false, false>(st, p, akc, bkc, grid);
   } else {
-    if (kseg) launch4<128, 128, true>(st, p, akc, bkc, grid);
-    else launch4<128, 128, false>(st, p, akc, bkc, grid);
+    if (kseg) launch4<128, 128, true, false>(st, p, akc, bkc, grid);
+    else if (epi) launch4<128, 128, false, true>(st, p, akc, bkc, grid);
+    else launch4<128, 128, false, false>(st, p, akc, bkc, grid);
   }
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }

@@ -182,9 +182,19 @@ def test_shard_export_import_roundtrip(dev):
         buf = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
         dev.schur_export_shard(buf)
         parts.append(buf)
-    dev.set_shard(0, 1)
     allbuf = torch.cat(parts)
-    dev.schur_import_all(allbuf)
+    dev.schur_import_all(allbuf)              # geometry of the 2-rank exchange
     H2 = dev.schur_get()
+    dev.set_shard(0, 1)
     dev.set_option("shard_bs", 128)
+    # the C library's exchange layout is the one loraine.jl_amd/sharding.py specifies
+    from loraine_jl_amd import sharding
+    sig = model.sigmaA[:, 0]
+    Hpos = np.tril(Hfull[np.ix_(sig, sig)])
+    for r in range(2):
+        mine = np.zeros_like(Hpos)
+        cols = sharding.owned_columns(model.n, r, 2, 16)
+        mine[:, cols] = Hpos[:, cols]
+        assert relerr(np.tril(sharding.unpack_all(np.concatenate([p.cpu().numpy() for p in parts]), model.n, 2, 16))[:, cols],
+                      mine[:, cols]) < 1e-15
     assert relerr(H2, Hfull) < 1e-15

@@ -1,0 +1,9 @@
+#!/bin/bash
+# 2-rank rehearsal of bench.py's sharded path on a 1-GPU box (gloo exchange through host memory).
+# Compares the sharded solve against the 1-rank solve on the same (small) synthetic problem.
+set -e
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+export LRN_BENCH_BACKEND=gloo LRN_BENCH_ONE_GPU=1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+   bench.py --gpus 2 --steps 2 --warmup 1 --msz 512 --nvar 700 --no-cpu-baseline
+python tools/check_sharded_solve.py
