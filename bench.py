@@ -45,6 +45,23 @@ def flops_model(msz, nvar):
     return 4.0 * nvar * msz ** 3 + float(nvar) ** 2 * msz ** 2 + nvar ** 3 / 3.0 + 8.0 * nvar ** 2
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per GEMM1 launch from the committed rocprofv3 --pmc passes (profiles/, same kernel,
+    same 32-matrix launch shape): (FETCH_SIZE + WRITE_SIZE) * 1024.  FETCH_SIZE is left uncorrected:
+    the guide's x2 rule is calibrated for 16 B/lane streams, these loads are 8 B/lane."""
+    import csv
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv"))):
+        vals = {}
+        for r in csv.DictReader(open(f)):
+            if r["kernel"].endswith("true, false, false, false>(lrn::GemmParams)") and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[r["counter"]] = float(r["mean"])
+        if len(vals) == 2:
+            best = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return best
+
+
 def make_scaling(msz, seed):
     import numpy as np
     rng = np.random.default_rng(seed)
@@ -211,7 +228,8 @@ def main():
             "algorithmic_tflops": flops_model(msz, nvar) / (ms_per_step * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128> GEMM1 P_k = A_k W (batched)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic_bytes() if (msz, world) == (2000, 1) else None,
                          "peak_probe": probe, "avg_launch_ms": t1, "launches_per_step": launches_per_step},
             "phase_ms_per_step": phases,
             "data_gen_s": t_gen,
