@@ -133,15 +133,15 @@ __global__ void lin_diag_kernel(const long* __restrict__ ptr, const int* __restr
 
 static int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
   const int m = b.msz;
-  GemmDesc g1;     // P = W M
+  GemmDesc g1;     // P = W M   (M symmetric: read as M[n + k*m] -> direct-to-LDS path)
   g1.A = b.W.as<double>(); g1.sAm = 1; g1.sAk = m;
-  g1.B = M; g1.sBk = 1; g1.sBn = m;
+  g1.B = M; g1.sBk = m; g1.sBn = 1;
   g1.C = P; g1.sCm = 1; g1.sCn = m;
   g1.M = g1.N = g1.K = m;
   LRN_TRY(gemm(c->stream, g1));
-  GemmDesc g2;     // Z = P W
+  GemmDesc g2;     // Z = P W   (W symmetric)
   g2.A = P; g2.sAm = 1; g2.sAk = m;
-  g2.B = b.W.as<double>(); g2.sBk = 1; g2.sBn = m;
+  g2.B = b.W.as<double>(); g2.sBk = m; g2.sBn = 1;
   g2.C = Z; g2.sCm = 1; g2.sCn = m;
   g2.M = g2.N = g2.K = m;
   return gemm(c->stream, g2);

@@ -217,6 +217,263 @@ static void launch4(hipStream_t st, const GemmParams& p, bool akc, bool bkc, dim
   else hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, KSEG, EPI>), grid, dim3(256), 0, st, p);
 }
 
+// ------------------------------------------------------------------ direct-to-LDS variant
+// Same tile / wave / MFMA structure as above for the case the hot Schur products are arranged
+// in: both operands contiguous along their non-K dimension (op(A)[m][k] = A[m + k*lda],
+// op(B)[k][n] = B[n + k*ldb], 16-byte aligned, even leading dimensions).  Each k-row of a
+// 128-wide tile is exactly one `buffer_load_dwordx4 ... lds` wave-instruction (64 lanes x 16 B
+// = 1 KiB) that lands in the padded [k][m] LDS image without touching VGPRs: no staging
+// registers, no ds_write pass, no per-element predicates -- rows beyond M/N and k-rows beyond K
+// are out of range of the buffer descriptor and read as zero.  Two LDS buffers, one barrier
+// per K-tile (the form the CDNA guide recommends when ~2 workgroups share a CU).
+template <bool EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
+  constexpr int LROW = BM + 16;                 // doubles per k-row of an image
+  constexpr int LA = BK * LROW;                 // doubles per image
+  __shared__ double lds[2 * 2 * LA];
+  const GemmDesc& d = p.d;
+  int tm, tn;
+  {
+    int bid = blockIdx.x, nwg = gridDim.x;
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int2 tt = p.tile_list[swz];
+    tm = tt.x;
+    tn = tt.y;
+  }
+  const int bz = blockIdx.z;
+  const double* Ag = d.A + (long)bz * d.bA;
+  const double* Bg = d.B + (long)bz * d.bB;
+  double* __restrict__ Cg = d.C + (long)bz * d.bC;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w & 1, wn = w >> 1;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lda = (int)d.sAk, ldb = (int)d.sBk;
+  // buffer descriptors: whole operand matrix of this batch element, K k-rows
+  // (an odd edge is rounded up to the pair: ld is even and >= M, so that element exists)
+  const int Me = d.M + (d.M & 1) <= lda ? d.M + (d.M & 1) : d.M;
+  const int Ne = d.N + (d.N & 1) <= ldb ? d.N + (d.N & 1) : d.N;
+  const unsigned bytesA = (unsigned)(((long)(d.K - 1) * lda + Me) * 8);
+  const unsigned bytesB = (unsigned)(((long)(d.K - 1) * ldb + Ne) * 8);
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bg, 0, bytesB, 0x00020000);
+  // per-lane in-row byte offset; lanes whose pair starts beyond the matrix edge go out of range
+  const int ma = m0 + 2 * lane, nb = n0 + 2 * lane;
+  const unsigned offA = ma < d.M ? (unsigned)ma * 8u : 0x80000000u;
+  const unsigned offB = nb < d.N ? (unsigned)nb * 8u : 0x80000000u;
+  const int nk = (d.K + BK - 1) / BK;
+
+  v4f64 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+  auto issue = [&](int kt, int buf) {
+    double* sa = lds + buf * (2 * LA);
+    double* sb = sa + LA;
+#pragma unroll
+    for (int j = 0; j < BK / 4; ++j) {
+      const int kr = w + 4 * j;                        // k-row of the tile handled by this wave
+      const unsigned krow = (unsigned)(kt * BK + kr);
+      // k-rows beyond K start at >= K*ld*8 > num_records -> zero fill
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + kr * LROW), 16,
+                                               (int)(offA + krow * (unsigned)lda * 8u), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + kr * LROW), 16,
+                                               (int)(offB + krow * (unsigned)ldb * 8u), 0, 0, 0);
+    }
+  };
+
+  const int fr = lane & 15, fk = lane >> 4;
+  issue(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+    const double* sa = lds + cur * (2 * LA);
+    const double* sb = sa + LA;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = sa[(kk * 4 + fk) * LROW + wm * 64 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = sb[(kk * 4 + fk) * LROW + wn * 64 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
+  const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
+  const bool sq = EPI && (d.flags & GEMM_SQUARE);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm * 64 + i * 16 + MFMA_F64_ROW(lane, r);
+        int n = n0 + wn * 64 + j * 16 + fr;
+        if (m < d.M && n < d.N) {
+          double v = alpha * acc[i][j][r];
+          if (sq) v = v * v;
+          double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
+          if (d.beta != 0.0) v += d.beta * (*c);
+          *c = v;
+        }
+      }
+}
+
+// ------------------------------------------------------------------ direct-to-LDS, K-contiguous
+// GEMM3 of the Schur assembly: H[i,j] = <A_i, T_j>, both operands contiguous along K (the vec
+// index of an msz x msz matrix), K walked in the lower-tile segments of GEMM_KSEG_TRI.
+// One `global_load_lds_dwordx4` wave-instruction fills 8 rows x 16 k (128 B each) of the
+// [m][k] image.  The image is unpadded (the DMA writes 1 KiB linearly), so the bank conflicts
+// of the fragment reads are removed by an XOR swizzle of the 16-byte k-pair index with
+// (row>>1)&7, applied to the SOURCE address and to the read (both-sides rule).  Rows beyond
+// M/N are clamped to the last valid row (their results are never stored).
+template <bool EPI_UNUSED>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
+  constexpr int LA = BM * BK;                   // doubles per image (unpadded)
+  __shared__ double lds[2 * 2 * LA];
+  const GemmDesc& d = p.d;
+  int tm, tn;
+  {
+    int bid = blockIdx.x, nwg = gridDim.x;
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int2 tt = p.tile_list[swz];
+    tm = tt.x;
+    tn = tt.y;
+  }
+  const int ks = blockIdx.z % d.ksplit;
+  const int bz = blockIdx.z / d.ksplit;
+  const double* Ag = d.A + (long)bz * d.bA;
+  const double* Bg = d.B + (long)bz * d.bB;
+  double* __restrict__ Cg = d.C + (long)bz * d.bC + (long)ks * d.sCs;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w & 1, wn = w >> 1;
+  const int m0 = tm * BM, n0 = tn * BN;
+  // staging geometry: instruction j of wave w covers image rows 8*(w + 4j) .. +7
+  const int lrow = lane >> 3, lpair = lane & 7;
+  const double* pa[4];
+  const double* pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int row = 8 * (w + 4 * j) + lrow;                  // tile-local row 0..127
+    int src_pair = lpair ^ ((row >> 1) & 7);           // swizzle on the source
+    int ra = m0 + row, rb = n0 + row;
+    if (ra >= d.M) ra = d.M - 1;
+    if (rb >= d.N) rb = d.N - 1;
+    pa[j] = Ag + (long)ra * d.sAm + 2 * src_pair;
+    pb[j] = Bg + (long)rb * d.sBn + 2 * src_pair;
+  }
+  int segc = p.kcols[ks], segcend = p.kcols[ks + 1];
+  int segr = (segc / 128) * 128;
+  const int ld = d.kseg_ld;
+
+  v4f64 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+  auto issue = [&](long kb, int buf) {
+    double* sa = lds + buf * (2 * LA);
+    double* sb = sa + LA;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r8 = 8 * (w + 4 * j);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kb),
+                                       (__attribute__((address_space(3))) void*)(sa + r8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j] + kb),
+                                       (__attribute__((address_space(3))) void*)(sb + r8 * BK), 16, 0, 0);
+    }
+  };
+  auto next_chunk = [&]() {
+    segr += BK;
+    if (segr >= ld) { ++segc; segr = (segc / 128) * 128; }
+  };
+
+  const int fr = lane & 15, fk = lane >> 4;
+  bool more = segc < segcend;
+  if (more) {
+    issue((long)segc * ld + segr, 0);
+    next_chunk();
+  }
+  __syncthreads();
+  int cur = 0;
+  while (more) {
+    const bool have_next = segc < segcend;
+    if (have_next) {
+      issue((long)segc * ld + segr, cur ^ 1);
+      next_chunk();
+    }
+    const double* sa = lds + cur * (2 * LA);
+    const double* sb = sa + LA;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double fa[TM], fb[TN];
+      const int k = kk * 4 + fk;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int row = wm * 64 + i * 16 + fr;
+        fa[i] = sa[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int row = wn * 64 + j * 16 + fr;
+        fb[j] = sb[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+    more = have_next;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm * 64 + i * 16 + MFMA_F64_ROW(lane, r);
+        int n = n0 + wn * 64 + j * 16 + fr;
+        if (m < d.M && n < d.N) Cg[(long)m * d.sCm + (long)n * d.sCn] = d.alpha * acc[i][j][r];
+      }
+}
+
+static bool kseg_lds_path_ok(const GemmDesc& d) {
+  if (d.sAk != 1 || d.sBk != 1 || d.beta != 0.0) return false;
+  if ((d.kseg_ld & 15) || (d.sAm & 1) || (d.sBn & 1) || (d.bA & 1) || (d.bB & 1)) return false;
+  if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return false;
+  if (d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE)) return false;
+  return true;
+}
+
+static bool lds_path_ok(const GemmDesc& d) {
+  if (d.sAm != 1 || d.sBn != 1 || d.ksplit != 1) return false;
+  if (d.sAk < d.M || d.sBk < d.N || (d.sAk & 1) || (d.sBk & 1)) return false;
+  if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || (d.bA & 1) || (d.bB & 1)) return false;
+  if (d.K < 1) return false;
+  // 32-bit byte offsets inside one operand matrix
+  if ((double)d.K * (double)d.sAk * 8.0 >= 2.0e9 || (double)d.K * (double)d.sBk * 8.0 >= 2.0e9) return false;
+  return true;
+}
+
 // (tm, tn) enumeration: 8x8 super-tiles (tm fastest inside), only the tiles a TRI flag keeps.
 // Consecutive list entries share operand panels, and the XCD swizzle hands each XCD a
 // contiguous run of the list, so co-resident workgroups of one L2 re-use panels.
@@ -306,6 +563,15 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   dim3 grid(ntile, 1, d.batch * d.ksplit);
   if (grid.z > 65535) return LRN_ERR_ARG;
   const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE);
+  if (kseg && kseg_lds_path_ok(d)) {
+    hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<false>), grid, dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
+  if (!small && !kseg && lds_path_ok(d)) {
+    if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f64_lds_kernel<false>), grid, dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
   if (small) {
     if (kseg) launch4<64, 64, true, false>(st, p, akc, bkc, grid);
     else if (epi) launch4<64, 64, false, true>(st, p, akc, bkc, grid);

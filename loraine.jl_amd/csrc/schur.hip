@@ -214,6 +214,38 @@ static inline unsigned nblocks(long n, int per = 256, long cap = 4096) {
   return (unsigned)b;
 }
 
+// Workgroup-slot quantisation: the chip holds 256 CUs x 2 workgroups of these GEMMs at once and
+// all workgroups of a launch take the same time, so a launch of `wgs` workgroups runs in
+// ceil(wgs / 512) rounds.  Pick batch sizes / split-K factors that fill the last round.
+static constexpr long WG_SLOTS = 512;
+static double fill_eff(long wgs) { return (double)wgs / (double)(((wgs + WG_SLOTS - 1) / WG_SLOTS) * WG_SLOTS); }
+
+static int pick_ksplit(long tiles, int max_split) {
+  int best = 1;
+  double beste = 0.0;
+  for (int k = 1; k <= max_split; ++k) {
+    if (tiles * k < WG_SLOTS && k < max_split) continue;
+    double e = fill_eff(tiles * k);
+    if (e >= 0.97) return k;
+    if (e > beste) { beste = e; best = k; }
+  }
+  return best;
+}
+
+static long pick_p_batch(int m, long limit) {
+  long t1 = (long)((m + 127) / 128) * ((m + 127) / 128);   // GEMM1 tiles per matrix
+  long tl = (long)((m + 127) / 128);
+  long t2 = tl * (tl + 1) / 2;                              // GEMM2 (lower) tiles per matrix
+  long best = std::min<long>(32, limit);
+  double beste = 0.0;
+  for (long bsz = std::min<long>(16, limit); bsz <= std::min<long>(96, limit); ++bsz) {
+    // time-weighted: GEMM1 does 2x the work per tile count ratio
+    double e = (2.0 * t1 * fill_eff(t1 * bsz) + (double)t2 * fill_eff(t2 * bsz)) / (2.0 * t1 + t2);
+    if (e > beste + 1e-9) { beste = e; best = bsz; }
+  }
+  return best;
+}
+
 static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   const int m = b.msz, nd = b.nd, n = c->nvar;
   const long mm = (long)m * m;
@@ -224,7 +256,7 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   if (c->T_cap == 0 || c->P_cap == 0) {
     size_t free_b = 0, total_b = 0;
     LRN_HIP(c, hipMemGetInfo(&free_b, &total_b));
-    long pcap = opt_p_batch > 0 ? opt_p_batch : 32;
+    long pcap = opt_p_batch > 0 ? opt_p_batch : pick_p_batch(m, nd);
     if (pcap > nd) pcap = nd;
     double avail = (double)free_b * 0.80 - (double)pcap * mm * 8.0 - 1.5e9;
     long tcap = (long)(avail / ((double)mm * 8.0));
@@ -263,17 +295,19 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
     for (int a = s0; a < s1; a += (int)c->P_cap) {
       int nb = std::min((int)c->P_cap, s1 - a);
       tic(c);
-      GemmDesc g1;   // P = A_a W
+      GemmDesc g1;   // P = A_a W, stored row-major (P^T) so that GEMM2 reads it n-contiguous;
+                     // W is symmetric, so it is read as W[n + k*m]: both operands stream
+                     // through the direct-to-LDS path
       g1.A = Ad + (long)a * mm; g1.sAm = 1; g1.sAk = m; g1.bA = mm;
-      g1.B = W; g1.sBk = 1; g1.sBn = m; g1.bB = 0;
-      g1.C = P; g1.sCm = 1; g1.sCn = m; g1.bC = mm;
+      g1.B = W; g1.sBk = m; g1.sBn = 1; g1.bB = 0;
+      g1.C = P; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
       g1.M = g1.N = g1.K = m; g1.batch = nb;
       LRN_TRY(gemm(c->stream, g1));
       toc(c, "gemm1");
       tic(c);
       GemmDesc g2;   // T = W P, lower tiles, strictly-lower x2
       g2.A = W; g2.sAm = 1; g2.sAk = m; g2.bA = 0;
-      g2.B = P; g2.sBk = 1; g2.sBn = m; g2.bB = mm;
+      g2.B = P; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
       g2.C = T + (long)(a - s0) * mm; g2.sCm = 1; g2.sCn = m; g2.bC = mm;
       g2.M = g2.N = g2.K = m; g2.batch = nb;
       g2.flags = GEMM_TRI_LOWER | GEMM_OFFDIAG_X2;
@@ -287,8 +321,7 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
       long tiles = 0;
       int tM = (M + TS - 1) / TS, tN = (N + TS - 1) / TS;
       for (int tn = 0; tn < tN; ++tn) tiles += std::max(0, tM - tn);
-      int ksplit = (int)std::min<long>(64, std::max<long>(1, (1536 + tiles - 1) / tiles));
-      ksplit = std::min(ksplit, std::max(1, m / 8));
+      int ksplit = pick_ksplit(tiles, std::min(64, std::max(1, m / 8)));
       size_t slab_bytes = (size_t)ksplit * M * N * 8;
       LRN_TRY(ensure(c, c->slabs, slab_bytes));
       GemmDesc g3;

@@ -43,6 +43,26 @@ def test_gemm_all_layouts(dev, M, N, K, tA, tB):
     assert relerr(C, ref) < 1e-14 * max(8, np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 64), (2000, 2176, 203), (2050, 2300, 17)])
+def test_gemm_direct_to_lds_path(dev, M, N, K):
+    """NT layout, even leading dimensions, >= 256 tiles: served by gemm_f64_lds_kernel
+    (buffer_load ... lds staging; edges and the K tail come from descriptor range checks)."""
+    from loraine_jl_amd import _capi
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K))
+    C0 = rng.standard_normal((M, N))
+    C = dev.dbg_gemm(A, B, False, True, alpha=1.25, beta=0.5, Cin=C0)
+    assert relerr(C, 1.25 * A @ B.T + 0.5 * C0) < 1e-14 * max(8, np.sqrt(K))
+    # triangular + x2 epilogue on the same path
+    if M == N:
+        C = dev.dbg_gemm(A, B, False, True, flags=_capi.GEMM_TRI_LOWER | _capi.GEMM_OFFDIAG_X2)
+        ref = A @ B.T
+        tiles = np.arange(M) // 128
+        low = tiles[:, None] > tiles[None, :]; dia = tiles[:, None] == tiles[None, :]
+        assert relerr(C[dia], ref[dia]) < 1e-13 and relerr(C[low], 2 * ref[low]) < 1e-13
+        assert not C[tiles[:, None] < tiles[None, :]].any()
+
+
 def test_gemm_splitk_matches(dev):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((5000, 300)); B = rng.standard_normal((5000, 260))
@@ -65,11 +85,12 @@ def test_gemm_tri_flags_and_square(dev):
     assert np.array_equal(C[0, n - 1], C0[0, n - 1])
 
 
-def test_gemm_packed_symmetric_dot(dev):
+@pytest.mark.parametrize("m", [300, 320])     # 320: K-contiguous direct-to-LDS kernel (msz % 16 == 0)
+def test_gemm_packed_symmetric_dot(dev, m):
     """GEMM2-style lower/x2 storage + GEMM3-style K-segment skipping reproduce full <A_i,T_j>."""
     from loraine_jl_amd import _capi
     rng = np.random.default_rng(7)
-    m, nv = 300, 150                      # msz (3 tiles of 128), constraints
+    nv = 150                              # constraints; msz = m (3 tiles of 128)
     Wm = rng.standard_normal((m, m)); Wm = Wm @ Wm.T / m
     As = rng.standard_normal((nv, m, m)); As = (As + As.transpose(0, 2, 1)) / 2
     Tfull = np.stack([Wm @ a @ Wm for a in As])
