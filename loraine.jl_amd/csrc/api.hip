@@ -11,6 +11,7 @@ extern double lrn_opt_dense_threshold;
 namespace lrn {
 void set_batch_opts(long t, long p);
 void prec_free(lrn_ctx* c);
+extern bool opt_jacobi_warm;
 }
 
 extern "C" {
@@ -52,6 +53,7 @@ int lrn_destroy(lrn_ctx* c) {
   lrn_free_model(c);
   release(c->info_dev);
   release(c->scratch);
+  release(c->jscratch);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -67,6 +69,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "profile")) c->profile = value != 0.0;
   else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
+  else if (!strcmp(key, "jacobi_warm")) lrn::opt_jacobi_warm = value != 0.0;
   else if (!strcmp(key, "shard_bs")) { if (value < 1) return LRN_ERR_ARG; c->shard_bs = (int)value; }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }
   else return set_error(c, LRN_ERR_ARG, "unknown option %s", key);

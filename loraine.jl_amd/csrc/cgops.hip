@@ -47,15 +47,20 @@ static inline unsigned nb(long n, long cap = 4096) {
 }
 
 // ------------------------------------------------------------------ AA' x  and  AA vec(Z)
-// M[q] = sum_k cq_v[k] * x[cq_j[k]] over the stored columns of AA (sparse constraints)
-__global__ void aat_gather_kernel(const long* __restrict__ cq_q, const long* __restrict__ cq_ptr,
-                                  const int* __restrict__ cq_j, const double* __restrict__ cq_v, long ncq,
-                                  const double* __restrict__ x, double* __restrict__ M) {
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ncq; t += (long)gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (long k = cq_ptr[t]; k < cq_ptr[t + 1]; ++k) s += cq_v[k] * x[cq_j[k]];
-    M[cq_q[t]] = s;
-  }
+// M[q] = sum_k cq_v[k] * x[cq_j[k]] over the stored columns of AA (sparse constraints):
+// one wavefront per stored column (a column can hold one entry per constraint -- e.g. the
+// shared corner of thetaG11's 1600 edge blocks), fixed lane partition -> deterministic.
+__global__ __launch_bounds__(256) void aat_gather_kernel(const long* __restrict__ cq_q, const long* __restrict__ cq_ptr,
+                                                         const int* __restrict__ cq_j, const double* __restrict__ cq_v,
+                                                         long ncq, const double* __restrict__ x, double* __restrict__ M) {
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ncq) return;
+  double s = 0.0;
+  for (long k = cq_ptr[t] + lane; k < cq_ptr[t + 1]; k += 64) s += cq_v[k] * x[cq_j[k]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) M[cq_q[t]] = s;
 }
 
 // M[q] -= sum_{p<nd} x[sigma[p]] * Adense[p][q]
@@ -178,7 +183,7 @@ int matvec_dev(lrn_ctx* c, const double* x, double* y) {
     double* M = c->m0.as<double>();
     LRN_HIP(c, hipMemsetAsync(M, 0, (size_t)mm * 8, c->stream));
     if (b.ncq > 0)
-      hipLaunchKernelGGL(aat_gather_kernel, dim3(nb(b.ncq)), dim3(256), 0, c->stream, b.cq_q.as<long>(),
+      hipLaunchKernelGGL(aat_gather_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, c->stream, b.cq_q.as<long>(),
                          b.cq_ptr.as<long>(), b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, M);
     if (b.nd > 0)
       hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>(), b.nd, mm,

@@ -25,34 +25,31 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
                                                          int* __restrict__ info) {
   __shared__ double a[NB][NB + 1];
   __shared__ double x[NB][NB + 1];
+  __shared__ double part[4][NB];
   __shared__ int bad;
   const int t = threadIdx.x;
+  const int ti = t & 63, tg = t >> 6;            // row, column group (4 groups)
   if (t == 0) bad = 0;
-  if (*info != 0) {          // earlier block already failed: leave data alone
-    return;
-  }
+  if (*info != 0) return;                        // an earlier block already failed
   for (int e = t; e < NB * NB; e += 256) {
     int i = e % NB, j = e / NB;
     a[i][j] = (i < nb && j < nb && i >= j) ? A[(long)i + (long)j * ld] : (i == j ? 1.0 : 0.0);
     x[i][j] = 0.0;
   }
   __syncthreads();
-  for (int j = 0; j < nb; ++j) {
+  // right-looking Cholesky: thread (ti, tg) owns row ti of the columns k == tg (mod 4)
+  for (int j = 0; j < NB; ++j) {
     double piv = a[j][j];
-    if (!(piv > 0.0)) {      // also catches NaN
+    if (!(piv > 0.0)) {                          // also catches NaN; uniform across the workgroup
       if (t == 0) bad = col0 + j + 1;
-      break;                 // uniform: every thread reads the same pivot
+      break;
     }
-    double ljj = sqrt(piv);
+    double rl = 1.0 / sqrt(piv);
+    double lij = a[ti][j] * rl;                  // scaled column entry of my row (valid for ti >= j)
     __syncthreads();
-    for (int i = j + t; i < nb; i += 256) a[i][j] = (i == j) ? ljj : a[i][j] / ljj;
+    if (tg == 0 && ti >= j) a[ti][j] = (ti == j) ? sqrt(piv) : lij;
     __syncthreads();
-    // trailing update, columns k > j, rows i >= k
-    int rem = nb - j - 1;
-    for (int e = t; e < rem * rem; e += 256) {
-      int i = j + 1 + e % rem, k = j + 1 + e / rem;
-      if (i >= k) a[i][k] -= a[i][j] * a[k][j];
-    }
+    for (int k = j + 1 + ((tg - (j + 1)) & 3); k <= ti; k += 4) a[ti][k] -= lij * a[k][j];
     __syncthreads();
   }
   __syncthreads();
@@ -60,19 +57,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
     if (t == 0) atomicCAS(info, 0, bad);
     return;
   }
-  // inverse, one column per thread (L x_c = e_c)
-  if (t < NB) {
-    int c = t;
-    if (c < nb) {
-      x[c][c] = 1.0 / a[c][c];
-      for (int i = c + 1; i < nb; ++i) {
-        double s = 0.0;
-        for (int k = c; k < i; ++k) s += a[i][k] * x[k][c];
-        x[i][c] = -s / a[i][i];
-      }
+  // inverse: L X = I, column c by the 4 threads {c, c+64, c+128, c+192}: partial sums over
+  // k == tg (mod 4), combined through LDS
+  for (int i = 0; i < NB; ++i) {
+    const int c = ti;
+    double s = 0.0;
+    if (c < i)
+      for (int k = c + tg; k < i; k += 4) s += a[i][k] * x[k][c];
+    part[tg][c] = s;
+    __syncthreads();
+    if (tg == 0) {
+      if (c == i) x[i][c] = 1.0 / a[i][i];
+      else if (c < i) x[i][c] = -(part[0][c] + part[1][c] + part[2][c] + part[3][c]) / a[i][i];
     }
+    __syncthreads();
   }
-  __syncthreads();
   for (int e = t; e < NB * NB; e += 256) {
     int i = e % NB, j = e / NB;
     if (i < nb && j < nb && i >= j) A[(long)i + (long)j * ld] = a[i][j];
@@ -175,9 +174,68 @@ __global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ 
   }
 }
 
+// whole L^-T L^-1 h in ONE workgroup (n <= POTRS_SMALL): 2*nblk dependent block steps without
+// launch gaps; the right-hand side lives in LDS.
+static constexpr int POTRS_SMALL = 2048;
+__global__ __launch_bounds__(1024) void potrs_small_kernel(const double* __restrict__ L, int ld, int n,
+                                                           const double* __restrict__ Linv,
+                                                           const double* __restrict__ h, double* __restrict__ x) {
+  __shared__ double r[POTRS_SMALL];
+  __shared__ double yb[NB];
+  const int t = threadIdx.x;
+  for (int i = t; i < n; i += 1024) r[i] = h[i];
+  __syncthreads();
+  const int nblk = (n + NB - 1) / NB;
+  for (int b = 0; b < nblk; ++b) {               // forward
+    const int k0 = b * NB, nbk = n - k0 < NB ? n - k0 : NB;
+    const double* Li = Linv + (long)b * NB * NB;
+    if (t < NB) {
+      double s = 0.0;
+      if (t < nbk)
+        for (int c = 0; c <= t; ++c) s += Li[t + c * NB] * r[k0 + c];
+      yb[t] = s;
+    }
+    __syncthreads();
+    if (t < nbk) r[k0 + t] = yb[t];
+    for (int row = k0 + nbk + t; row < n; row += 1024) {
+      const double* Lr = L + row + (long)k0 * ld;
+      double s = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < nbk; ++c) s += Lr[(long)c * ld] * yb[c];
+      r[row] -= s;
+    }
+    __syncthreads();
+  }
+  for (int b = nblk - 1; b >= 0; --b) {          // backward
+    const int k0 = b * NB, nbk = n - k0 < NB ? n - k0 : NB;
+    const double* Li = Linv + (long)b * NB * NB;
+    if (t < NB) {
+      double s = 0.0;
+      if (t < nbk)
+        for (int i = t; i < nbk; ++i) s += Li[i + t * NB] * r[k0 + i];
+      yb[t] = s;
+    }
+    __syncthreads();
+    if (t < nbk) r[k0 + t] = yb[t];
+    for (int c = t; c < k0; c += 1024) {
+      const double* Lc = L + k0 + (long)c * ld;
+      double s = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < nbk; ++i) s += Lc[i] * yb[i];
+      r[c] -= s;
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += 1024) x[i] = r[i];
+}
+
 // x = L^{-T} L^{-1} h ; r is scratch (n doubles); x may alias h? no: h is read-only.
 int potrs_vec(hipStream_t st, const double* L, int n, int ld, const double* Linv, const double* h,
               double* x, double* r, double* y) {
+  if (n <= POTRS_SMALL) {
+    hipLaunchKernelGGL(potrs_small_kernel, dim3(1), dim3(1024), 0, st, L, ld, n, Linv, h, x);
+    return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
   hipMemcpyAsync(r, h, (size_t)n * 8, hipMemcpyDeviceToDevice, st);
   int nblk = (n + NB - 1) / NB;
   for (int b = 0; b < nblk; ++b) {

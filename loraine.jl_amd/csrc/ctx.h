@@ -35,6 +35,8 @@ struct LmiBlock {
   lrn::DBuf b_ptr, b_col, b_val;
   // --- NT scaling state (device, msz x msz col-major)
   lrn::DBuf X, S, W, G, Gi, Si, D, DDsi;
+  lrn::DBuf Vprev;          // right singular vectors of the previous prepare_W (Jacobi warm start)
+  bool have_Vprev = false;
   bool have_W = false, have_G = false;
 };
 
@@ -69,7 +71,7 @@ struct lrn_ctx {
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // generic scratch
-  lrn::DBuf scratch;
+  lrn::DBuf scratch, jscratch;
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
 };

@@ -8,6 +8,8 @@
 // column pairs -> one workgroup per pair.
 //   * n <= 96: one workgroup keeps A and V in LDS and runs all sweeps in one launch.
 //   * larger n: one launch per round (n-1 rounds per sweep), columns streamed from L2/MALL.
+#include <algorithm>
+
 #include "ctx.h"
 #include "jacobi.h"
 
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void jacobi_round_kernel(double* __restrict__ 
 // whole SVD in one workgroup, n <= JAC_SMALL
 __global__ __launch_bounds__(256) void jacobi_small_kernel(double* __restrict__ A, double* __restrict__ V,
                                                           int n, double tol, int max_sweeps,
-                                                          int* __restrict__ sweeps_out) {
+                                                          int* __restrict__ sweeps_out, int v_init) {
   extern __shared__ double smem[];
   double* a = smem;                 // n x n, column stride n+1
   double* v = smem + (size_t)n * (n + 1);
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(double* __restrict__ 
   for (int e = t; e < n * n; e += 256) {
     int i = e % n, j = e / n;
     a[i + j * ld] = A[e];
-    if (V) v[i + j * ld] = (i == j) ? 1.0 : 0.0;
+    if (V) v[i + j * ld] = v_init ? V[e] : ((i == j) ? 1.0 : 0.0);
   }
   __syncthreads();
   const int np = (n + 1) & ~1;
@@ -139,6 +141,191 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(double* __restrict__ 
   if (t == 0 && sweeps_out) *sweeps_out = sweep;
 }
 
+// ------------------------------------------------------------------ blocked rounds
+// Block one-sided Jacobi on 16-column blocks; a round = nbk/2 disjoint block pairs (I,J), and
+// every pair's n x 32 panel P = [A_I A_J] is split into row chunks so that a round fills the
+// chip.  Three launches per round:
+//   jb_gram_kernel    partial Gram matrices P_chunk' P_chunk        (FP64 MFMA)
+//   jb_rotate_kernel  G = sum of partials; one parallel-ordered cyclic sweep of plane rotations
+//                     on the 32x32 Gram matrix in LDS (same rotation formula / threshold as
+//                     the scalar kernel), accumulated in R
+//   jb_apply_kernel   P <- P R and V_panel <- V_panel R              (FP64 MFMA)
+// nbk-1 rounds make every pair of columns meet once per sweep.
+static constexpr int JB = 16;
+
+__global__ __launch_bounds__(256) void jb_gram_kernel(const double* __restrict__ A, int n, int nbk2, int round,
+                                                      int RC, double* __restrict__ Gpart) {
+  __shared__ double part[4][3][256];
+  int I, J;
+  rr_pair(nbk2, round, blockIdx.x, &I, &J);
+  const int cI = I * JB, cJ = J * JB;
+  if (cI >= n) return;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int ci = lane & 15, kq = lane >> 4;
+  v4f64 aII = {0, 0, 0, 0}, aIJ = aII, aJJ = aII;
+  const bool okI = cI + ci < n, okJ = cJ + ci < n;
+  const double* pI = A + (long)(cI + ci) * n;
+  const double* pJ = A + (long)(cJ + ci) * n;
+  const int rbeg = blockIdx.y * RC, rend = min(n, rbeg + RC);
+  for (int r0 = rbeg + 4 * w; r0 < rend; r0 += 16) {
+    int row = r0 + kq;
+    double xI = (okI && row < rend) ? pI[row] : 0.0;
+    double xJ = (okJ && row < rend) ? pJ[row] : 0.0;
+    aII = __builtin_amdgcn_mfma_f64_16x16x4f64(xI, xI, aII, 0, 0, 0);
+    aIJ = __builtin_amdgcn_mfma_f64_16x16x4f64(xI, xJ, aIJ, 0, 0, 0);
+    aJJ = __builtin_amdgcn_mfma_f64_16x16x4f64(xJ, xJ, aJJ, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int i = kq + 4 * r;                         // f64 C/D map: row = (lane>>4) + 4*reg, col = lane&15
+    part[w][0][i * 16 + ci] = aII[r];
+    part[w][1][i * 16 + ci] = aIJ[r];
+    part[w][2][i * 16 + ci] = aJJ[r];
+  }
+  __syncthreads();
+  double* out = Gpart + ((long)blockIdx.x * gridDim.y + blockIdx.y) * 768;
+  for (int e = t; e < 768; e += 256) {
+    int tile = e >> 8, o = e & 255;
+    out[e] = part[0][tile][o] + part[1][tile][o] + part[2][tile][o] + part[3][tile][o];
+  }
+}
+
+// Plane-rotation parameters that annihilate the (p,q) Gram entry (Hestenes / same formula as the
+// scalar kernel); returns false when the pair is already orthogonal to tolerance.
+__device__ __forceinline__ bool jrot(double al, double be, double ga, double tol, double* c, double* s) {
+  *c = 1.0; *s = 0.0;
+  if (!(ga * ga > tol * tol * al * be)) return false;      // |ga| > tol sqrt(al be), also rejects NaN
+  // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), written with one
+  // division:  t = 2 ga / (d + sign(d) sqrt(d^2 + 4 ga^2)),  d = be - al
+  double d = be - al, g2 = 2.0 * ga;
+  double h = sqrt(d * d + g2 * g2);
+  double tt = g2 / (d >= 0.0 ? d + h : d - h);
+  double cc = 1.0 / sqrt(1.0 + tt * tt);
+  *c = cc;
+  *s = cc * tt;
+  return true;
+}
+
+// One cyclic sweep over the 32x32 Gram matrix: 31 steps of 16 disjoint rotations.  With
+// J = diag of the step's 2x2 rotations, G' = J'GJ decomposes into 256 independent 2x2 blocks
+// (pair k1 x pair k2) -> one thread per block, every thread recomputes the two rotations it
+// needs from the diagonal blocks, G is double-buffered: ONE barrier per step.
+__global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict__ Gpart, int nchunk, int n, int nbk2,
+                                                        int round, double tol, double* __restrict__ Rbuf,
+                                                        int* __restrict__ flags, int* __restrict__ nrot) {
+  __shared__ double G[2][32][33];
+  __shared__ double R[32][33];
+  __shared__ unsigned char sched[31][16][2];   // round-robin schedule of the 32 local columns
+  __shared__ int anyrot;
+  int I, J;
+  rr_pair(nbk2, round, blockIdx.x, &I, &J);
+  const int t = threadIdx.x;
+  if (I * JB >= n) {
+    if (t == 0) flags[blockIdx.x] = 0;
+    return;
+  }
+  if (t == 0) anyrot = 0;
+  for (int e = t; e < 31 * 16; e += 256) {
+    int p, q;
+    rr_pair(32, e >> 4, e & 15, &p, &q);
+    sched[e >> 4][e & 15][0] = (unsigned char)p;
+    sched[e >> 4][e & 15][1] = (unsigned char)q;
+  }
+  const double* gp = Gpart + (long)blockIdx.x * nchunk * 768;
+  for (int e = t; e < 1024; e += 256) {
+    int i = e >> 5, j = e & 31;
+    int tile, ii, jj;
+    if (i < 16 && j < 16) { tile = 0; ii = i; jj = j; }
+    else if (i < 16) { tile = 1; ii = i; jj = j - 16; }
+    else if (j < 16) { tile = 1; ii = j; jj = i - 16; }      // G_JI = G_IJ'
+    else { tile = 2; ii = i - 16; jj = j - 16; }
+    int o = tile * 256 + ii * 16 + jj;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += gp[(long)c * 768 + o];
+    G[0][i][j] = s;
+    R[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int k1 = t >> 4, k2 = t & 15;
+  int cur = 0;
+  bool rotated = false;
+  for (int step = 0; step < 31; ++step) {
+    const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
+    const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
+    double c1, s1, c2, s2;
+    bool r1 = jrot(G[cur][p1][p1], G[cur][q1][q1], G[cur][p1][q1], tol, &c1, &s1);
+    bool r2 = jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
+    rotated |= r1 | r2;
+    // 2x2 block (pair k1 rows, pair k2 columns):  B' = J1' B J2
+    double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
+    double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
+    double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
+    G[cur ^ 1][p1][p2] = c1 * t00 - s1 * t10;
+    G[cur ^ 1][p1][q2] = c1 * t01 - s1 * t11;
+    G[cur ^ 1][q1][p2] = s1 * t00 + c1 * t10;
+    G[cur ^ 1][q1][q2] = s1 * t01 + c1 * t11;
+    // R <- R J: rows k1 and k1+16, column pair k2 (each element owned by one thread)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int i = k1 + 16 * h;
+      double x = R[i][p2], y = R[i][q2];
+      R[i][p2] = c2 * x - s2 * y;
+      R[i][q2] = s2 * x + c2 * y;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (rotated) anyrot = 1;
+  __syncthreads();
+  double* ro = Rbuf + (long)blockIdx.x * 1024;
+  for (int e = t; e < 1024; e += 256) ro[e] = R[e >> 5][e & 31];
+  if (t == 0) {
+    flags[blockIdx.x] = anyrot;
+    if (anyrot) atomicAdd(nrot, 1);
+  }
+}
+
+// (P R)' = R' P': output rows land on consecutive lanes (coalesced loads and stores)
+__global__ __launch_bounds__(256) void jb_apply_kernel(double* __restrict__ A, double* __restrict__ V, int n, int nbk2,
+                                                       int round, int RC, const double* __restrict__ Rbuf,
+                                                       const int* __restrict__ flags) {
+  __shared__ double R[32][33];
+  if (!flags[blockIdx.x]) return;
+  double* Mx = blockIdx.z == 0 ? A : V;
+  int I, J;
+  rr_pair(nbk2, round, blockIdx.x, &I, &J);
+  const int cI = I * JB, cJ = J * JB;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int ci = lane & 15, kq = lane >> 4;
+  const double* ri = Rbuf + (long)blockIdx.x * 1024;
+  for (int e = t; e < 1024; e += 256) R[e >> 5][e & 31] = ri[e];
+  __syncthreads();
+  const int rbeg = blockIdx.y * RC, rend = min(n, rbeg + RC);
+  for (int r0 = rbeg + 16 * w; r0 < rend; r0 += 64) {
+    const int row = r0 + ci;
+    double pk[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      int k = 4 * ks + kq;
+      int col = k < 16 ? cI + k : cJ + k - 16;
+      pk[ks] = (row < rend && col < n) ? Mx[(long)row + (long)col * n] : 0.0;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      v4f64 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(R[4 * ks + kq][16 * h + ci], pk[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = kq + 4 * r;                      // output column within the half
+        int col = h == 0 ? cI + m : cJ + m;
+        if (row < rend && col < n) Mx[(long)row + (long)col * n] = acc[r];
+      }
+    }
+  }
+}
+
 __global__ void set_identity_kernel(double* __restrict__ V, int n) {
   long total = (long)n * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
@@ -154,7 +341,7 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
   if (threadIdx.x == 0) sig[blockIdx.x] = sqrt(s);
 }
 
-int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* sweeps_out) {
+int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* sweeps_out, bool v_init) {
   hipStream_t st = c->stream;
   const double tol = 2.220446049250313e-16 * sqrt((double)(n > 4 ? n : 4));
   const int max_sweeps = 40;
@@ -164,16 +351,32 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
   if (n <= JAC_SMALL) {
     size_t sh = (size_t)2 * n * (n + 1) * 8;
     hipFuncSetAttribute((const void*)jacobi_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(256), sh, st, A, V, n, tol, max_sweeps, cnt);
+    hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(256), sh, st, A, V, n, tol, max_sweeps, cnt, v_init ? 1 : 0);
     LRN_HIP(c, hipMemcpyAsync(&sweeps, cnt, 4, hipMemcpyDeviceToHost, st));
     LRN_HIP(c, hipStreamSynchronize(st));
   } else {
-    if (V) hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, st, V, n);
-    const int np = (n + 1) & ~1;
+    if (V && !v_init) hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, st, V, n);
+    const int nbk = (n + JB - 1) / JB;
+    const int nbk2 = (nbk + 1) & ~1;
+    const int npair = nbk2 / 2;
+    int nchunk = (512 + npair - 1) / npair;
+    nchunk = std::max(1, std::min(nchunk, (n + 63) / 64));
+    int RC = (n + nchunk - 1) / nchunk;
+    RC = ((RC + 63) / 64) * 64;
+    nchunk = (n + RC - 1) / RC;
+    LRN_TRY(ensure(c, c->jscratch, ((size_t)npair * nchunk * 768 + (size_t)npair * 1024) * 8 + (size_t)npair * 4 + 64));
+    double* Gpart = c->jscratch.as<double>();
+    double* Rbuf = Gpart + (size_t)npair * nchunk * 768;
+    int* flags = reinterpret_cast<int*>(Rbuf + (size_t)npair * 1024);
     for (; sweeps < max_sweeps;) {
       LRN_HIP(c, hipMemsetAsync(cnt, 0, 4, st));
-      for (int round = 0; round < np - 1; ++round)
-        hipLaunchKernelGGL(jacobi_round_kernel, dim3(np / 2), dim3(256), 0, st, A, V, n, np, round, tol, cnt);
+      for (int round = 0; round < nbk2 - 1; ++round) {
+        hipLaunchKernelGGL(jb_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
+        hipLaunchKernelGGL(jb_rotate_kernel, dim3(npair), dim3(256), 0, st, Gpart, nchunk, n, nbk2, round, tol, Rbuf,
+                           flags, cnt);
+        hipLaunchKernelGGL(jb_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
+                           Rbuf, flags);
+      }
       int h = 0;
       LRN_HIP(c, hipMemcpyAsync(&h, cnt, 4, hipMemcpyDeviceToHost, st));
       LRN_HIP(c, hipStreamSynchronize(st));

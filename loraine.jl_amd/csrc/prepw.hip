@@ -91,6 +91,8 @@ static int gemm_nn(hipStream_t st, int n, const double* A, bool tA, const double
   return gemm(st, g);
 }
 
+bool opt_jacobi_warm = true;
+
 int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   const int n = b.msz;
   const size_t mm = (size_t)n * n * 8;
@@ -128,10 +130,21 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   // CC = LS' LX ; SVD
   tic(c);
   LRN_TRY(gemm_nn(st, n, LS, true, LX, false, CC));
+  // warm start: the right singular vectors of the previous IP iterate nearly orthogonalise
+  // the columns of the new CC, so Jacobi starts from CC*V_prev with V = V_prev
+  bool warm = b.have_Vprev && opt_jacobi_warm;
+  if (warm) {
+    LRN_TRY(gemm_nn(st, n, CC, false, b.Vprev.as<double>(), false, Y));
+    LRN_HIP(c, hipMemcpyAsync(CC, Y, mm, hipMemcpyDeviceToDevice, st));
+    LRN_HIP(c, hipMemcpyAsync(V, b.Vprev.p, mm, hipMemcpyDeviceToDevice, st));
+  }
   toc(c, "prepw_gemm");
   tic(c);
   int sweeps = 0;
-  LRN_TRY(jacobi_svd(c, CC, V, b.D.as<double>(), n, &sweeps));
+  LRN_TRY(jacobi_svd(c, CC, V, b.D.as<double>(), n, &sweeps, warm));
+  LRN_TRY(ensure(c, b.Vprev, mm));
+  LRN_HIP(c, hipMemcpyAsync(b.Vprev.p, V, mm, hipMemcpyDeviceToDevice, st));
+  b.have_Vprev = true;
   c->counts["svd_sweeps"] = sweeps;
   toc(c, "prepw_svd");
   tic(c);

@@ -441,7 +441,8 @@ class MySolver:
                 sigma=self.sigma, cg_pre=self.cg_iter_pre, cg_cor=self.cg_iter_cor, itertime=self.itertime,
                 gpu_ms=dict(prepare_w=d.timing("prepare_w"), assemble=d.timing("assemble"),
                             factor=d.timing("factor"), solve=d.timing("solve"),
-                            prec_setup=d.timing("prec_setup"), pcg=d.timing("pcg"))))
+                            prec_setup=d.timing("prec_setup"), pcg=d.timing("pcg"), svd=d.timing("prepw_svd")),
+                svd_sweeps=d.count("svd_sweeps")))
             if self.preconditioner == 4:
                 n_ = self.model.n
                 if ((self.cg_iter_cor / 2 > self.erank * self.model.nlmi * math.sqrt(n_) / 20
