@@ -106,6 +106,40 @@ int lrn_prec_apply(lrn_ctx* ctx, const double* x, double* Mx);
 int lrn_pcg(lrn_ctx* ctx, const double* h, double tol, int maxit, double* x, int* exit_code,
             int* iters);
 
+/* ---- device-resident iterate (find_step, check_convergence, RHS) ---
+ * The matrix variables X, S, Rd, delX, delS, Xn, Sn, RNT live on the device; only nvar-/nlin-
+ * vectors and scalars cross the boundary.  All functions act on every LMI block at once unless
+ * they take `ilmi`. */
+/* C[ilmi] = -A[ilmi,1] dense msz x msz (src/model.jl:133) */
+int lrn_ip_set_c(lrn_ctx* ctx, int ilmi, const double* C);
+/* initial point X = Eps*I, S = Eta*I (src/initial_point.jl:33,42) or any iterate */
+int lrn_ip_set_iterate(lrn_ctx* ctx, int ilmi, const double* X, const double* S);
+int lrn_ip_get_iterate(lrn_ctx* ctx, int ilmi, double* X, double* S);
+/* X (which=1) or S (which=2) += eps*I : try_cholesky's regularisation (src/prepare_W.jl:14) */
+int lrn_ip_add_diag(lrn_ctx* ctx, int ilmi, int which, double eps);
+/* prepare_W on the resident X, S (src/prepare_W.jl:28-94); info as lrn_prepare_w */
+int lrn_ip_prepare_w(lrn_ctx* ctx, int ilmi, int* info);
+/* out = sum_i AA[i]*vec(X[i])   (src/predictor_corrector.jl:12) */
+int lrn_ip_aa_x(lrn_ctx* ctx, double* out);
+/* Rd[i] = C[i] - S[i] - mat(AA[i]'y)   (src/predictor_corrector.jl:13) */
+int lrn_ip_residual_d(lrn_ctx* ctx, const double* y);
+/* out = sum_i AA[i]*vec(W(Rd+S)W)   (makeRHS without Rp, src/makeBBBB.jl:221-228) */
+int lrn_ip_rhs_pred(lrn_ctx* ctx, double* out);
+/* out = sum_i AA[i]*my_kron(G,G, G'RdG + D - sigma_mu./D - RNT)   (src/predictor_corrector.jl:186) */
+int lrn_ip_rhs_corr(lrn_ctx* ctx, double sigma_mu, double* out);
+/* delS, delX and the per-block step lengths alpha[nlmi], beta[nlmi]
+ * (src/predictor_corrector.jl:248-291; eigmin by Lanczos on the device) */
+int lrn_ip_find_step(lrn_ctx* ctx, int predict, double sigma_mu, double tau, const double* dely,
+                     double* alpha, double* beta);
+/* predict=1: Xn, Sn, RNT with the per-block steps, trXnSn[nlmi] returned (:302-311);
+ * predict=0: X, S updated and re-symmetrised with alpha[0], beta[0] (:313-322) */
+int lrn_ip_update(lrn_ctx* ctx, int predict, const double* alpha, const double* beta, double* trXnSn);
+/* per block 5 numbers: <X,S>, eigmin(X), eigmin(S), ||Rd||_F, <C,X>
+ * (find_mu src/Solvers.jl:480-494, check_convergence :496-511) */
+int lrn_ip_stats(lrn_ctx* ctx, double* out5);
+/* smallest eigenvalue of a symmetric n x n matrix (unit test of the Lanczos kernel) */
+int lrn_dbg_eigmin(lrn_ctx* ctx, int n, const double* M, double* lam, int* steps);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* milliseconds of the named phase in the last call that ran it, measured with HIP events
  * on the context's stream ("gemm1","gemm2","gemm3","sparse","assemble","factor","solve",...);

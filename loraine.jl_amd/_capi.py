@@ -45,6 +45,19 @@ SIGNATURES = {
     "lrn_prec_setup": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, PI]),
     "lrn_prec_apply": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     "lrn_pcg": (C.c_int, [c_ctx, C.c_void_p, C.c_double, C.c_int, C.c_void_p, PI, PI]),
+    "lrn_ip_set_c": (C.c_int, [c_ctx, C.c_int, C.c_void_p]),
+    "lrn_ip_set_iterate": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_void_p]),
+    "lrn_ip_get_iterate": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_void_p]),
+    "lrn_ip_add_diag": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_double]),
+    "lrn_ip_prepare_w": (C.c_int, [c_ctx, C.c_int, PI]),
+    "lrn_ip_aa_x": (C.c_int, [c_ctx, C.c_void_p]),
+    "lrn_ip_residual_d": (C.c_int, [c_ctx, C.c_void_p]),
+    "lrn_ip_rhs_pred": (C.c_int, [c_ctx, C.c_void_p]),
+    "lrn_ip_rhs_corr": (C.c_int, [c_ctx, C.c_double, C.c_void_p]),
+    "lrn_ip_find_step": (C.c_int, [c_ctx, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrn_ip_update": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrn_ip_stats": (C.c_int, [c_ctx, C.c_void_p]),
+    "lrn_dbg_eigmin": (C.c_int, [c_ctx, C.c_int, C.c_void_p, PD, PI]),
     "lrn_get_timing": (C.c_int, [c_ctx, C.c_char_p, PD]),
     "lrn_get_count": (C.c_int64, [c_ctx, C.c_char_p]),
     "lrn_mfma_f64_peak": (C.c_int, [c_ctx, PD]),

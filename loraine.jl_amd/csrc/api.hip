@@ -54,6 +54,9 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->info_dev);
   release(c->scratch);
   release(c->jscratch);
+  release(c->redbuf);
+  release(c->redout);
+  release(c->lzbuf);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);

@@ -136,7 +136,7 @@ __global__ void lin_diag_kernel(const long* __restrict__ ptr, const int* __restr
   for (long k = ptr[l]; k < ptr[l + 1]; ++k) atomicAdd(&d[row[k]], val[k] * val[k] * xs[l]);
 }
 
-static int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
+int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
   const int m = b.msz;
   GemmDesc g1;     // P = W M   (M symmetric: read as M[n + k*m] -> direct-to-LDS path)
   g1.A = b.W.as<double>(); g1.sAm = 1; g1.sAk = m;
@@ -152,7 +152,7 @@ static int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
   return gemm(c->stream, g2);
 }
 
-static int ensure_m(lrn_ctx* c, int m) {
+int ensure_m(lrn_ctx* c, int m) {
   size_t mm = (size_t)m * m * 8;
   LRN_TRY(ensure(c, c->m0, mm));
   LRN_TRY(ensure(c, c->m1, mm));
@@ -161,7 +161,7 @@ static int ensure_m(lrn_ctx* c, int m) {
 }
 
 // y += AA vec(Z)
-static int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
+int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
   if (b.npos_nz > b.nd)
     hipLaunchKernelGGL(aa_times_kernel, dim3((b.npos_nz - b.nd + 3) / 4), dim3(256), 0, c->stream, b.ent_ptr.as<long>(),
                        b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(), Z, b.msz, b.nd, b.npos_nz,
@@ -172,23 +172,30 @@ static int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
   return LRN_OK;
 }
 
+// M = mat(AA' x)  (symmetrised msz x msz, kron_etc.jl:13-18)
+int aat_to_mat(lrn_ctx* c, LmiBlock& b, const double* x, double* M) {
+  const int m = b.msz;
+  const long mm = (long)m * m;
+  LRN_HIP(c, hipMemsetAsync(M, 0, (size_t)mm * 8, c->stream));
+  if (b.ncq > 0)
+    hipLaunchKernelGGL(aat_gather_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, c->stream, b.cq_q.as<long>(),
+                       b.cq_ptr.as<long>(), b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, M);
+  if (b.nd > 0)
+    hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>(), b.nd, mm,
+                       b.sigma_d.as<int>(), x, M);
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, m);
+  return LRN_OK;
+}
+
 int matvec_dev(lrn_ctx* c, const double* x, double* y) {
   const int n = c->nvar;
   LRN_HIP(c, hipMemsetAsync(y, 0, (size_t)n * 8, c->stream));
   for (auto& b : c->lmi) {
     if (!b.have_W) return set_error(c, LRN_ERR_STATE, "W not set");
     const int m = b.msz;
-    const long mm = (long)m * m;
     LRN_TRY(ensure_m(c, m));
     double* M = c->m0.as<double>();
-    LRN_HIP(c, hipMemsetAsync(M, 0, (size_t)mm * 8, c->stream));
-    if (b.ncq > 0)
-      hipLaunchKernelGGL(aat_gather_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, c->stream, b.cq_q.as<long>(),
-                         b.cq_ptr.as<long>(), b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, M);
-    if (b.nd > 0)
-      hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>(), b.nd, mm,
-                         b.sigma_d.as<int>(), x, M);
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, m);
+    LRN_TRY(aat_to_mat(c, b, x, M));
     LRN_TRY(wmw(c, b, M, c->m1.as<double>(), c->m2.as<double>()));
     LRN_TRY(aa_times(c, b, c->m2.as<double>(), y));
   }

@@ -36,6 +36,9 @@ struct LmiBlock {
   // --- NT scaling state (device, msz x msz col-major)
   lrn::DBuf X, S, W, G, Gi, Si, D, DDsi;
   lrn::DBuf Vprev;          // right singular vectors of the previous prepare_W (Jacobi warm start)
+  // --- device-resident iterate (ipstep.hip): C, residual, directions, predictor point
+  lrn::DBuf Cd, Rd, delX, delS, Xn, Sn, RNT, t0, t1, t2;
+  bool resident = false;
   bool have_Vprev = false;
   bool have_W = false, have_G = false;
 };
@@ -71,7 +74,7 @@ struct lrn_ctx {
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // generic scratch
-  lrn::DBuf scratch, jscratch;
+  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf;
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
 };

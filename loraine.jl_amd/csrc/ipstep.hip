@@ -1,0 +1,569 @@
+// Device-resident interior-point step: everything of the reference's per-iteration host work
+// that touches msz x msz matrices:
+//   residual Rd, right-hand sides (makeRHS, corrector my_kron term), find_step with its two
+//   extreme-eigenvalue problems per block, the predictor point / RNT, the iterate update and
+//   the matrix parts of find_mu / check_convergence.
+// Reference: src/predictor_corrector.jl:8-16,186,248-326 ; src/Solvers.jl:480-511 ;
+// src/kron_etc.jl.  nvar-/nlin-vectors and scalars stay with the host driver.
+//
+// eigmin (predictor_corrector.jl:272,285; Solvers.jl:503,505) is a Lanczos iteration on the
+// device: y = M q on all CUs (bandwidth-bound symmetric mat-vec), one fused single-workgroup
+// kernel per step for alpha, the three-term update and beta, no host sync inside a batch of
+// steps; the host only bisects the tiny tridiagonal matrix.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/loraine_hip.h"
+#include "ops.h"
+
+namespace lrn {
+
+static inline unsigned nbk(long n, long cap = 4096) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// out = a*A + b*B + c*C (null pointers skipped), n elements
+__global__ void lin3_kernel(double* __restrict__ out, double a, const double* __restrict__ A, double b,
+                            const double* __restrict__ B, double c, const double* __restrict__ C, long n) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    double v = 0.0;
+    if (A) v += a * A[e];
+    if (B) v += b * B[e];
+    if (C) v += c * C[e];
+    out[e] = v;
+  }
+}
+
+// out = (M + M')/2 (out may alias M only through the symmetric access pattern -> use a separate out)
+__global__ void sym_kernel(const double* __restrict__ M, double* __restrict__ out, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    out[e] = 0.5 * (M[e] + M[(long)j + (long)i * n]);
+  }
+}
+
+// Q = sym( dd_j * M[i,j] * dd_i )   (predictor_corrector.jl:268-269)
+__global__ void scale_sym_kernel(const double* __restrict__ M, const double* __restrict__ dd, double* __restrict__ out, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    out[e] = 0.5 * dd[i] * dd[j] * (M[e] + M[(long)j + (long)i * n]);
+  }
+}
+
+// RNT = -(Mx + Mx') ./ (D_i + D_j)   (predictor_corrector.jl:308-309)
+__global__ void rnt_kernel(const double* __restrict__ Mx, const double* __restrict__ D, double* __restrict__ out, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    out[e] = -(Mx[e] + Mx[(long)j + (long)i * n]) / (D[i] + D[j]);
+  }
+}
+
+// inner = G'RdG + diag(D - sigma_mu/D) - RNT    (predictor_corrector.jl:186)
+__global__ void corr_inner_kernel(const double* __restrict__ GRG, const double* __restrict__ D, const double* __restrict__ RNT,
+                                  double sigma_mu, double* __restrict__ out, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    double v = GRG[e] - RNT[e];
+    if (i == j) v += D[i] - sigma_mu / D[i];
+    out[e] = v;
+  }
+}
+
+__global__ void add_diag_mat_kernel(double* __restrict__ M, int n, double eps) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) M[(long)i * n + i] += eps;
+}
+
+// two-stage reductions: partial[b] = sum A.*B (B may be null -> A.*A)
+__global__ __launch_bounds__(256) void dot_part_kernel(const double* __restrict__ A, const double* __restrict__ B, long n,
+                                                       double* __restrict__ part) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) s += A[e] * (B ? B[e] : A[e]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void dot_final_kernel(const double* __restrict__ part, int np, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int e = threadIdx.x; e < np; e += 256) s += part[e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+static int mm(lrn_ctx* c, int n, const double* A, bool tA, const double* B, bool tB, double* C) {
+  GemmDesc g;
+  g.A = A; g.B = B; g.C = C;
+  g.M = g.N = g.K = n;
+  if (!tA) { g.sAm = 1; g.sAk = n; } else { g.sAm = n; g.sAk = 1; }
+  if (!tB) { g.sBk = 1; g.sBn = n; } else { g.sBk = n; g.sBn = 1; }
+  g.sCm = 1; g.sCn = n;
+  return gemm(c->stream, g);
+}
+
+static int dot_dev(lrn_ctx* c, const double* A, const double* B, long n, double* out_dev) {
+  const int np = (int)std::min<long>(1024, (n + 255) / 256);
+  LRN_TRY(ensure(c, c->redbuf, (size_t)(np + 64) * 8));
+  hipLaunchKernelGGL(dot_part_kernel, dim3(np), dim3(256), 0, c->stream, A, B, n, c->redbuf.as<double>());
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, c->stream, c->redbuf.as<double>(), np, out_dev);
+  return LRN_OK;
+}
+
+// ------------------------------------------------------------------ Lanczos eigmin
+__global__ void lz_init_kernel(double* __restrict__ q, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)i * 2654435761u + 12345u;     // fixed pseudo-random start vector
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  q[i] = ((double)h / 4294967296.0) - 0.5;
+}
+
+// ypart[chunk][i] = sum_{j in chunk} M[i + j*n] q[j]
+__global__ __launch_bounds__(256) void symv_part_kernel(const double* __restrict__ M, int n, int cper,
+                                                        const double* __restrict__ q, double* __restrict__ ypart) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int c0 = blockIdx.y * cper, c1 = min(n, c0 + cper);
+  double s = 0.0;
+  for (int j = c0; j < c1; ++j) s += M[(long)i + (long)j * n] * q[j];
+  ypart[(long)blockIdx.y * n + i] = s;
+}
+
+__device__ __forceinline__ double wg_sum1024b(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < 16; ++i) s += sh[i];
+  return s;
+}
+
+// one Lanczos step (no re-orthogonalisation): w = sum ypart; a = q.w; w -= a q + b_prev q_prev;
+// b = ||w||; q_next = w / b.   j == -1: just normalise q in place (start vector).
+__global__ __launch_bounds__(1024) void lz_step_kernel(const double* __restrict__ ypart, int nchunk, int n, int j,
+                                                       double* __restrict__ q, double* __restrict__ qprev,
+                                                       double* __restrict__ w, double* __restrict__ ab) {
+  __shared__ double sh[16];
+  const int t = threadIdx.x;
+  if (j < 0) {
+    double s = 0.0;
+    for (int i = t; i < n; i += 1024) s += q[i] * q[i];
+    s = wg_sum1024b(s, sh);
+    double r = 1.0 / sqrt(s);
+    for (int i = t; i < n; i += 1024) { q[i] *= r; qprev[i] = 0.0; }
+    return;
+  }
+  const double bprev = j > 0 ? ab[2 * (j - 1) + 1] : 0.0;
+  double a = 0.0;
+  for (int i = t; i < n; i += 1024) {
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += ypart[(long)k * n + i];
+    w[i] = s;
+    a += q[i] * s;
+  }
+  a = wg_sum1024b(a, sh);
+  double b2 = 0.0;
+  for (int i = t; i < n; i += 1024) {
+    double v = w[i] - a * q[i] - bprev * qprev[i];
+    w[i] = v;
+    b2 += v * v;
+  }
+  b2 = wg_sum1024b(b2, sh);
+  double b = sqrt(b2);
+  double r = b > 0.0 ? 1.0 / b : 0.0;
+  for (int i = t; i < n; i += 1024) {
+    double qi = q[i];
+    qprev[i] = qi;
+    q[i] = w[i] * r;
+  }
+  if (t == 0) { ab[2 * j] = a; ab[2 * j + 1] = b; }
+}
+
+// smallest eigenvalue of the symmetric tridiagonal (a_0..a_{m-1}; b_0..b_{m-2}) by bisection
+static double tridiag_min(const std::vector<double>& a, const std::vector<double>& b, int m) {
+  double lo = a[0], hi = a[0];
+  for (int i = 0; i < m; ++i) {
+    double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < m - 1 ? std::fabs(b[i]) : 0.0);
+    lo = std::min(lo, a[i] - r);
+    hi = std::max(hi, a[i] + r);
+  }
+  auto count_below = [&](double x) {   // number of eigenvalues < x (Sturm sequence)
+    int cnt = 0;
+    double d = 1.0;
+    for (int i = 0; i < m; ++i) {
+      double bb = i > 0 ? b[i - 1] * b[i - 1] : 0.0;
+      d = a[i] - x - (i > 0 ? bb / d : 0.0);
+      if (d == 0.0) d = -1e-300;
+      if (d < 0.0) ++cnt;
+    }
+    return cnt;
+  };
+  for (int it = 0; it < 200; ++it) {
+    double mid = 0.5 * (lo + hi);
+    if (mid == lo || mid == hi) break;
+    if (count_below(mid) >= 1) hi = mid; else lo = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+// |beta_m * s_m| for the Ritz pair (theta, s) of T_m: the residual norm ||M v - theta v|| of the
+// Ritz vector, a rigorous bound on the distance from theta to the spectrum.  s by two steps of
+// inverse iteration on the tridiagonal matrix (Thomas algorithm with a tiny shift).
+static double ritz_residual(const std::vector<double>& a, const std::vector<double>& b, int m, double theta) {
+  if (m <= 1) return 0.0;
+  std::vector<double> s(m, 1.0 / std::sqrt((double)m)), d(m), u(m), y(m);
+  double scale = 0.0;
+  for (int i = 0; i < m; ++i) scale = std::max(scale, std::fabs(a[i]) + (i < m - 1 ? std::fabs(b[i]) : 0.0));
+  const double shift = theta - 1e-13 * std::max(scale, 1e-300) - 1e-300;
+  for (int it = 0; it < 3; ++it) {
+    // solve (T - shift I) y = s  (T - shift I is positive definite up to rounding)
+    d[0] = a[0] - shift;
+    if (d[0] == 0.0) d[0] = 1e-300;
+    u[0] = s[0];
+    for (int i = 1; i < m; ++i) {
+      double l = b[i - 1] / d[i - 1];
+      d[i] = a[i] - shift - l * b[i - 1];
+      if (d[i] == 0.0) d[i] = 1e-300;
+      u[i] = s[i] - l * u[i - 1];
+    }
+    y[m - 1] = u[m - 1] / d[m - 1];
+    for (int i = m - 2; i >= 0; --i) y[i] = (u[i] - b[i] * y[i + 1]) / d[i];
+    double nrm = 0.0;
+    for (int i = 0; i < m; ++i) nrm += y[i] * y[i];
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0.0) || !std::isfinite(nrm)) return std::fabs(b[m - 1]);
+    for (int i = 0; i < m; ++i) s[i] = y[i] / nrm;
+  }
+  return std::fabs(b[m - 1] * s[m - 1]);
+}
+
+int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out) {
+  hipStream_t st = c->stream;
+  if (n == 1) {
+    LRN_TRY(copy_out(c, lam, M, 8));
+    if (steps_out) *steps_out = 1;
+    return LRN_OK;
+  }
+  // without re-orthogonalisation the extreme Ritz value may need more than n steps
+  const int mmax = std::min(1500, 4 * n + 40);
+  int nchunk = std::max(1, std::min(64, (int)(512 / std::max(1, (n + 255) / 256))));
+  nchunk = std::min(nchunk, std::max(1, n / 16));
+  const int cper = (n + nchunk - 1) / nchunk;
+  nchunk = (n + cper - 1) / cper;
+  LRN_TRY(ensure(c, c->lzbuf, ((size_t)3 * n + (size_t)nchunk * n + 2 * (size_t)mmax + 64) * 8));
+  double* q = c->lzbuf.as<double>();
+  double* qprev = q + n;
+  double* w = qprev + n;
+  double* ypart = w + n;
+  double* ab = ypart + (size_t)nchunk * n;
+  hipLaunchKernelGGL(lz_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q, n);
+  hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, st, ypart, nchunk, n, -1, q, qprev, w, ab);
+  std::vector<double> a, b, hab;
+  double theta_prev = 0.0, theta = 0.0, scale = 0.0;
+  int m = 0;
+  bool have_prev = false;
+  const int batch = n <= 16 ? n : 16;
+  while (m < mmax) {
+    int m1 = std::min(mmax, m + batch);
+    for (int j = m; j < m1; ++j) {
+      hipLaunchKernelGGL(symv_part_kernel, dim3((n + 255) / 256, nchunk), dim3(256), 0, st, M, n, cper, q, ypart);
+      hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, st, ypart, nchunk, n, j, q, qprev, w, ab);
+    }
+    hab.resize(2 * (size_t)m1);
+    LRN_TRY(copy_out(c, hab.data(), ab, (size_t)2 * m1 * 8));
+    a.resize(m1); b.resize(m1);
+    int mm_ = m1;
+    for (int j = 0; j < m1; ++j) {
+      a[j] = hab[2 * j]; b[j] = hab[2 * j + 1];
+      scale = std::max(scale, std::fabs(a[j]) + std::fabs(b[j]));
+      if (!(b[j] > 1e-14 * scale) && j + 1 < m1) { mm_ = j + 1; break; }      // invariant subspace
+    }
+    theta = tridiag_min(a, b, mm_);
+    m = m1;
+    if (mm_ < m1) break;
+    // stop on the rigorous residual bound; for a clearly non-negative spectrum (theta > 0 is an
+    // upper bound of lambda_min) the callers only need the sign class once theta has settled
+    double res = ritz_residual(a, b, mm_, theta);
+    if (res <= 1e-11 * std::max(std::fabs(theta), 1e-4 * scale)) break;
+    if (have_prev && theta > 0.0 && std::fabs(theta - theta_prev) <= 1e-3 * theta && m >= 64) break;
+    theta_prev = theta;
+    have_prev = true;
+  }
+  *lam = theta;
+  if (steps_out) *steps_out = m;
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
+// ------------------------------------------------------------------ resident step
+static int ensure_resident(lrn_ctx* c, LmiBlock& b) {
+  size_t mm_ = (size_t)b.msz * b.msz * 8;
+  for (DBuf* d : {&b.Cd, &b.Rd, &b.delX, &b.delS, &b.Xn, &b.Sn, &b.RNT, &b.t0, &b.t1, &b.t2})
+    if (d->bytes < mm_) LRN_TRY(ensure(c, *d, mm_, true));
+  b.resident = true;
+  return LRN_OK;
+}
+
+}  // namespace lrn
+
+using namespace lrn;
+
+#define BLK(il)                                                        \
+  if (!c || (il) < 0 || (il) >= c->nlmi) return LRN_ERR_ARG;          \
+  LRN_HIP(c, hipSetDevice(c->device));                                 \
+  LmiBlock& b = c->lmi[(il)];                                          \
+  LRN_TRY(ensure_resident(c, b));                                      \
+  const size_t mm_ = (size_t)b.msz * b.msz * 8;                        \
+  (void)mm_;
+
+extern "C" int lrn_ip_set_c(lrn_ctx* c, int il, const double* C) {
+  BLK(il);
+  if (!C) return LRN_ERR_ARG;
+  return copy_in(c, b.Cd.p, C, mm_);
+}
+
+extern "C" int lrn_ip_set_iterate(lrn_ctx* c, int il, const double* X, const double* S) {
+  BLK(il);
+  if (!X || !S) return LRN_ERR_ARG;
+  LRN_TRY(copy_in(c, b.X.p, X, mm_));
+  LRN_TRY(copy_in(c, b.S.p, S, mm_));
+  LRN_HIP(c, hipMemsetAsync(b.RNT.p, 0, mm_, c->stream));
+  b.have_Vprev = false;
+  return LRN_OK;
+}
+
+extern "C" int lrn_ip_get_iterate(lrn_ctx* c, int il, double* X, double* S) {
+  BLK(il);
+  if (X) LRN_TRY(copy_out(c, X, b.X.p, mm_));
+  if (S) LRN_TRY(copy_out(c, S, b.S.p, mm_));
+  return LRN_OK;
+}
+
+extern "C" int lrn_ip_add_diag(lrn_ctx* c, int il, int which, double eps) {
+  BLK(il);
+  if (which != 1 && which != 2) return LRN_ERR_ARG;
+  hipLaunchKernelGGL(add_diag_mat_kernel, dim3((b.msz + 255) / 256), dim3(256), 0, c->stream,
+                     (which == 1 ? b.X : b.S).as<double>(), b.msz, eps);
+  return LRN_OK;
+}
+
+extern "C" int lrn_ip_prepare_w(lrn_ctx* c, int il, int* info) {
+  BLK(il);
+  if (!info) return LRN_ERR_ARG;
+  hipEvent_t a0, a1;
+  if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
+  LRN_TRY(prepare_w_block(c, b, info));
+  if (c->profile) {
+    (void)hipEventRecord(a1, c->stream); (void)hipEventSynchronize(a1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["prepare_w"] += ms; c->counts["prepare_w"] += 1;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+  }
+  return LRN_OK;
+}
+
+extern "C" int lrn_ip_aa_x(lrn_ctx* c, double* out) {
+  if (!c || !out) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_HIP(c, hipMemsetAsync(c->v1.p, 0, (size_t)n * 8, c->stream));
+  for (auto& b : c->lmi) LRN_TRY(aa_times(c, b, b.X.as<double>(), c->v1.as<double>()));
+  return copy_out(c, out, c->v1.p, (size_t)n * 8);
+}
+
+extern "C" int lrn_ip_residual_d(lrn_ctx* c, const double* y) {
+  if (!c || !y) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  LRN_TRY(copy_in(c, c->v0.p, y, (size_t)c->nvar * 8));
+  for (auto& b : c->lmi) {
+    LRN_TRY(ensure_resident(c, b));
+    const long mm_ = (long)b.msz * b.msz;
+    LRN_TRY(aat_to_mat(c, b, c->v0.as<double>(), b.t0.as<double>()));
+    hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.Rd.as<double>(), 1.0, b.Cd.as<double>(),
+                       -1.0, b.S.as<double>(), -1.0, b.t0.as<double>(), mm_);
+  }
+  return LRN_OK;
+}
+
+extern "C" int lrn_ip_rhs_pred(lrn_ctx* c, double* out) {
+  if (!c || !out) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_HIP(c, hipMemsetAsync(c->v1.p, 0, (size_t)n * 8, c->stream));
+  for (auto& b : c->lmi) {
+    LRN_TRY(ensure_resident(c, b));
+    const long mm_ = (long)b.msz * b.msz;
+    hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t0.as<double>(), 1.0, b.Rd.as<double>(),
+                       1.0, b.S.as<double>(), 0.0, (const double*)nullptr, mm_);
+    LRN_TRY(wmw(c, b, b.t0.as<double>(), b.t1.as<double>(), b.t2.as<double>()));
+    LRN_TRY(aa_times(c, b, b.t2.as<double>(), c->v1.as<double>()));
+  }
+  return copy_out(c, out, c->v1.p, (size_t)n * 8);
+}
+
+extern "C" int lrn_ip_rhs_corr(lrn_ctx* c, double sigma_mu, double* out) {
+  if (!c || !out) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_HIP(c, hipMemsetAsync(c->v1.p, 0, (size_t)n * 8, c->stream));
+  for (auto& b : c->lmi) {
+    LRN_TRY(ensure_resident(c, b));
+    const int m = b.msz;
+    const long mm_ = (long)m * m;
+    double* G = b.G.as<double>();
+    // t1 = G' Rd G
+    LRN_TRY(mm(c, m, G, true, b.Rd.as<double>(), false, b.t0.as<double>()));
+    LRN_TRY(mm(c, m, b.t0.as<double>(), false, G, false, b.t1.as<double>()));
+    hipLaunchKernelGGL(corr_inner_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t1.as<double>(), b.D.as<double>(),
+                       b.RNT.as<double>(), sigma_mu, b.t0.as<double>(), m);
+    // my_kron(G,G,inner) = vec(G inner G')
+    LRN_TRY(mm(c, m, G, false, b.t0.as<double>(), false, b.t1.as<double>()));
+    LRN_TRY(mm(c, m, b.t1.as<double>(), false, G, true, b.t2.as<double>()));
+    LRN_TRY(aa_times(c, b, b.t2.as<double>(), c->v1.as<double>()));
+  }
+  return copy_out(c, out, c->v1.p, (size_t)n * 8);
+}
+
+extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double tau, const double* dely,
+                                double* alpha, double* beta) {
+  if (!c || !dely || !alpha || !beta) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  LRN_TRY(copy_in(c, c->v0.p, dely, (size_t)c->nvar * 8));
+  hipEvent_t a0, a1;
+  if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
+  for (int il = 0; il < c->nlmi; ++il) {
+    LmiBlock& b = c->lmi[il];
+    LRN_TRY(ensure_resident(c, b));
+    const int m = b.msz;
+    const long mm_ = (long)m * m;
+    const unsigned g = nbk(mm_);
+    double *t0 = b.t0.as<double>(), *t1 = b.t1.as<double>(), *t2 = b.t2.as<double>();
+    double *G = b.G.as<double>(), *Gi = b.Gi.as<double>();
+    // delS = Rd - mat(AA' dely)                                   (:252)
+    LRN_TRY(aat_to_mat(c, b, c->v0.as<double>(), t0));
+    hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, b.delS.as<double>(), 1.0, b.Rd.as<double>(), -1.0, t0,
+                       0.0, (const double*)nullptr, mm_);
+    // t2 = W delS W                                                (:253)
+    LRN_TRY(wmw(c, b, b.delS.as<double>(), t1, t2));
+    if (predict) {
+      // delX = mat(-X - W delS W)                                  (:255)
+      hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, -1.0, b.X.as<double>(), -1.0, t2, 0.0,
+                         (const double*)nullptr, mm_);
+    } else {
+      // delX = mat(sigma_mu Si - X - W delS W + G RNT G')          (:257)
+      hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, sigma_mu, b.Si.as<double>(), -1.0,
+                         b.X.as<double>(), -1.0, t2, mm_);
+      LRN_TRY(mm(c, m, G, false, b.RNT.as<double>(), false, t1));
+      LRN_TRY(mm(c, m, t1, false, G, true, t2));
+      hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, t0, 1.0, t2, 0.0, (const double*)nullptr, mm_);
+    }
+    hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.delX.as<double>(), m);
+    // step lengths: eigmin of DDsi-scaled G' delS G and Gi delX Gi'   (:263-291)
+    double lamX = 0.0, lamS = 0.0;
+    LRN_TRY(mm(c, m, Gi, false, b.delX.as<double>(), false, t0));
+    LRN_TRY(mm(c, m, t0, false, Gi, true, t1));
+    hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t2, m);
+    LRN_TRY(eigmin_dev(c, t2, m, &lamX, nullptr));
+    LRN_TRY(mm(c, m, G, true, b.delS.as<double>(), false, t0));
+    LRN_TRY(mm(c, m, t0, false, G, false, t1));
+    hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t2, m);
+    LRN_TRY(eigmin_dev(c, t2, m, &lamS, nullptr));
+    alpha[il] = lamX > -1e-6 ? 0.99 : std::min(1.0, -tau / lamX);
+    beta[il] = lamS > -1e-6 ? 0.99 : std::min(1.0, -tau / lamS);
+  }
+  if (c->profile) {
+    (void)hipEventRecord(a1, c->stream); (void)hipEventSynchronize(a1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, a0, a1);
+    c->timing["find_step"] += ms; c->counts["find_step"] += 1;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+  }
+  return LRN_OK;
+}
+
+extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const double* beta, double* trXnSn) {
+  if (!c || !alpha || !beta) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  std::vector<double> tr(c->nlmi, 0.0);
+  LRN_TRY(ensure(c, c->redout, 64 * 8));
+  for (int il = 0; il < c->nlmi; ++il) {
+    LmiBlock& b = c->lmi[il];
+    LRN_TRY(ensure_resident(c, b));
+    const int m = b.msz;
+    const long mm_ = (long)m * m;
+    const unsigned g = nbk(mm_);
+    double *t0 = b.t0.as<double>(), *t1 = b.t1.as<double>(), *t2 = b.t2.as<double>();
+    if (predict) {
+      hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, b.Xn.as<double>(), 1.0, b.X.as<double>(), alpha[il],
+                         b.delX.as<double>(), 0.0, (const double*)nullptr, mm_);
+      hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, b.Sn.as<double>(), 1.0, b.S.as<double>(), beta[il],
+                         b.delS.as<double>(), 0.0, (const double*)nullptr, mm_);
+      // RNT = -(Gi delX delS G + its transpose) ./ (D_i + D_j)     (:308-309)
+      LRN_TRY(mm(c, m, b.Gi.as<double>(), false, b.delX.as<double>(), false, t0));
+      LRN_TRY(mm(c, m, t0, false, b.delS.as<double>(), false, t1));
+      LRN_TRY(mm(c, m, t1, false, b.G.as<double>(), false, t2));
+      hipLaunchKernelGGL(rnt_kernel, dim3(g), dim3(256), 0, c->stream, t2, b.D.as<double>(), b.RNT.as<double>(), m);
+      LRN_TRY(dot_dev(c, b.Xn.as<double>(), b.Sn.as<double>(), mm_, c->redout.as<double>() + il));
+    } else {
+      hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, b.X.as<double>(), alpha[0],
+                         b.delX.as<double>(), 0.0, (const double*)nullptr, mm_);
+      hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.X.as<double>(), m);
+      hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, b.S.as<double>(), beta[0],
+                         b.delS.as<double>(), 0.0, (const double*)nullptr, mm_);
+      hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.S.as<double>(), m);
+    }
+  }
+  if (predict && trXnSn && c->nlmi > 0) LRN_TRY(copy_out(c, trXnSn, c->redout.p, (size_t)c->nlmi * 8));
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
+extern "C" int lrn_ip_stats(lrn_ctx* c, double* out5) {
+  if (!c || !out5) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  LRN_TRY(ensure(c, c->redout, (size_t)std::max(64, 5 * c->nlmi) * 8));
+  for (int il = 0; il < c->nlmi; ++il) {
+    LmiBlock& b = c->lmi[il];
+    LRN_TRY(ensure_resident(c, b));
+    const long mm_ = (long)b.msz * b.msz;
+    double* o = c->redout.as<double>() + 5 * il;
+    LRN_TRY(dot_dev(c, b.X.as<double>(), b.S.as<double>(), mm_, o + 0));
+    LRN_TRY(dot_dev(c, b.Rd.as<double>(), nullptr, mm_, o + 3));
+    LRN_TRY(dot_dev(c, b.Cd.as<double>(), b.X.as<double>(), mm_, o + 4));
+  }
+  LRN_TRY(copy_out(c, out5, c->redout.p, (size_t)5 * c->nlmi * 8));
+  for (int il = 0; il < c->nlmi; ++il) {
+    LmiBlock& b = c->lmi[il];
+    double lx = 0, ls = 0;
+    LRN_TRY(eigmin_dev(c, b.X.as<double>(), b.msz, &lx, nullptr));
+    LRN_TRY(eigmin_dev(c, b.S.as<double>(), b.msz, &ls, nullptr));
+    out5[5 * il + 1] = lx;
+    out5[5 * il + 2] = ls;
+    out5[5 * il + 3] = std::sqrt(out5[5 * il + 3]);
+  }
+  return LRN_OK;
+}
+
+extern "C" int lrn_dbg_eigmin(lrn_ctx* c, int n, const double* M, double* lam, int* steps) {
+  if (!c || n <= 0 || !M || !lam) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf d;
+  LRN_TRY(ensure(c, d, (size_t)n * n * 8));
+  LRN_TRY(copy_in(c, d.p, M, (size_t)n * n * 8));
+  int rc = eigmin_dev(c, d.as<double>(), n, lam, steps);
+  release(d);
+  return rc;
+}

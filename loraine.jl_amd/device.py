@@ -264,3 +264,71 @@ class Device:
         self._chk(self.lib.lrn_dbg_svd_jacobi(self.h, n, ptr(A), ptr(U), ptr(V), ptr(s), C.byref(sw)),
                   "lrn_dbg_svd_jacobi")
         return U, s, V, sw.value
+
+    # ------------------------------------------------------------------ device-resident iterate
+    def ip_set_c(self, ilmi, Cm):
+        Cm = f64(Cm)
+        self._chk(self.lib.lrn_ip_set_c(self.h, ilmi, ptr(Cm)), "lrn_ip_set_c")
+
+    def ip_set_iterate(self, ilmi, X, S):
+        X = f64(X); S = f64(S)
+        self._chk(self.lib.lrn_ip_set_iterate(self.h, ilmi, ptr(X), ptr(S)), "lrn_ip_set_iterate")
+
+    def ip_get_iterate(self, ilmi):
+        m = self.msizes[ilmi]
+        X = np.zeros((m, m), order="F"); S = np.zeros((m, m), order="F")
+        self._chk(self.lib.lrn_ip_get_iterate(self.h, ilmi, ptr(X), ptr(S)), "lrn_ip_get_iterate")
+        return X, S
+
+    def ip_add_diag(self, ilmi, which, eps):
+        self._chk(self.lib.lrn_ip_add_diag(self.h, ilmi, int(which), float(eps)), "lrn_ip_add_diag")
+
+    def ip_prepare_w(self, ilmi):
+        info = C.c_int(0)
+        self._chk(self.lib.lrn_ip_prepare_w(self.h, ilmi, C.byref(info)), "lrn_ip_prepare_w")
+        return info.value
+
+    def _vec_out(self, fn, name, *args):
+        out = np.zeros(self.nvar)
+        self._chk(fn(self.h, *args, ptr(out)), name)
+        return out
+
+    def ip_aa_x(self):
+        return self._vec_out(self.lib.lrn_ip_aa_x, "lrn_ip_aa_x")
+
+    def ip_residual_d(self, y):
+        y = f64(y)
+        self._chk(self.lib.lrn_ip_residual_d(self.h, ptr(y)), "lrn_ip_residual_d")
+
+    def ip_rhs_pred(self):
+        return self._vec_out(self.lib.lrn_ip_rhs_pred, "lrn_ip_rhs_pred")
+
+    def ip_rhs_corr(self, sigma_mu):
+        return self._vec_out(self.lib.lrn_ip_rhs_corr, "lrn_ip_rhs_corr", C.c_double(sigma_mu))
+
+    def ip_find_step(self, predict, sigma_mu, tau, dely):
+        dely = f64(dely)
+        nl = max(1, len(self.msizes))
+        a = np.zeros(nl); b = np.zeros(nl)
+        self._chk(self.lib.lrn_ip_find_step(self.h, int(predict), float(sigma_mu), float(tau), ptr(dely), ptr(a), ptr(b)),
+                  "lrn_ip_find_step")
+        return a[:len(self.msizes)], b[:len(self.msizes)]
+
+    def ip_update(self, predict, alpha, beta):
+        nl = max(1, len(self.msizes))
+        a = np.zeros(nl); b = np.zeros(nl); tr = np.zeros(nl)
+        a[:len(np.atleast_1d(alpha))] = alpha; b[:len(np.atleast_1d(beta))] = beta
+        self._chk(self.lib.lrn_ip_update(self.h, int(predict), ptr(a), ptr(b), ptr(tr)), "lrn_ip_update")
+        return tr[:len(self.msizes)]
+
+    def ip_stats(self):
+        nl = len(self.msizes)
+        out = np.zeros(5 * max(1, nl))
+        self._chk(self.lib.lrn_ip_stats(self.h, ptr(out)), "lrn_ip_stats")
+        return out[:5 * nl].reshape(nl, 5)
+
+    def dbg_eigmin(self, M):
+        M = f64(M)
+        lam = C.c_double(0.0); st = C.c_int(0)
+        self._chk(self.lib.lrn_dbg_eigmin(self.h, M.shape[0], ptr(M), C.byref(lam), C.byref(st)), "lrn_dbg_eigmin")
+        return lam.value, st.value

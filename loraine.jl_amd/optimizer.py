@@ -29,7 +29,10 @@ class UnsupportedAttribute(KeyError):
 
 
 class Optimizer:
-    def __init__(self, device=None, device_index=0):
+    def __init__(self, device=None, device_index=0, resident=True):
+        # resident=True: X, S and all msz x msz work stay on the device (resident.ResidentSolver);
+        # resident=False: step-length search / convergence test in host NumPy (solvers.MySolver)
+        self.resident = resident
         self.solver = None
         self.halpha = None
         self.max_sense = False
@@ -84,13 +87,14 @@ class Optimizer:
         opts = dict(self.options)
         if self.silent:
             opts["verb"] = 0
-        self.solver, self.halpha = solvers.load(model, opts, device=self._device) if self._device is not None \
-            else self._load_own(model, opts)
-
-    def _load_own(self, model, opts):
-        from .device import Device
-        self._device = Device(self._device_index)
-        return solvers.load(model, opts, device=self._device)
+        if self._device is None:
+            from .device import Device
+            self._device = Device(self._device_index)
+        if self.resident:
+            from . import resident
+            self.solver, self.halpha = resident.load(model, opts, device=self._device)
+        else:
+            self.solver, self.halpha = solvers.load(model, opts, device=self._device)
 
     def optimize(self):                        # MOI.optimize! (:136-140)
         if self._pending is None:

@@ -1,0 +1,92 @@
+"""GPU: device-resident IP step (find_step / check_convergence / RHS on the device, Lanczos
+eigmin) against the host-NumPy driver and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from oracle import loraine_oracle as lo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import loraine_jl_amd
+    d = loraine_jl_amd.Device(0)
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 33, 50, 300, 801])
+@pytest.mark.parametrize("kind", ["indef", "spd", "cluster"])
+def test_lanczos_eigmin(dev, n, kind):
+    rng = np.random.default_rng(n + len(kind))
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    if kind == "indef":
+        lam = rng.standard_normal(n)
+    elif kind == "spd":
+        lam = np.logspace(-6, 2, n)
+    else:
+        lam = np.concatenate([np.full(max(1, n // 2), -0.3), np.linspace(1, 2, n - max(1, n // 2))])[:n]
+    M = (Q * lam) @ Q.T
+    M = (M + M.T) / 2
+    ref = float(sla.eigvalsh(M, subset_by_index=[0, 0])[0])
+    got, steps = dev.dbg_eigmin(M)
+    nrm = np.abs(lam).max()
+    assert got >= ref - 1e-12 * nrm                      # a Ritz value never undershoots lambda_min
+    if ref < -1e-3 * nrm or n <= 8:
+        # the regime the step-length rule needs (predictor_corrector.jl:274-278): tight
+        assert abs(got - ref) <= 1e-10 * max(abs(ref), 1e-3 * nrm), (got, ref, steps)
+    else:
+        # positive (semi)definite with eigenvalues clustered at the small end: only the sign class
+        # "lambda_min > -1e-6" is consumed (0.99 step / zero DIMACS err2, err4)
+        assert (got > -1e-6) == (ref > -1e-6), (got, ref, steps)
+
+
+def _run(path, resident, **opts):
+    from loraine_jl_amd.optimizer import Optimizer
+    o = Optimizer(resident=resident)
+    o.set_silent(True)
+    for k, v in opts.items():
+        o.set_attribute(k, v)
+    o.read_from_file(path)
+    o.optimize()
+    return o
+
+
+def test_theta1_resident_matches_oracle_trace():
+    opts = dict(kit=0, eDIMACS=1e-6, initpoint=1, aamat=2)
+    path = os.path.join(GOLD, "theta1.dat-s")
+    o = _run(path, True, **opts)
+    ref = lo.MySolver(lo.model_from_sdpa(path), dict(opts, verb=0))
+    lo.solve(ref)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.solver.iter == ref.iter
+    assert o.objective_value() == pytest.approx(lo.objective_value(ref), rel=1e-8)
+    assert o.dual_objective_value() == pytest.approx(lo.dual_objective_value(ref), rel=1e-8)
+    for tg, tr in zip(o.solver.trace, ref.trace):
+        assert tg["primal_obj"] == pytest.approx(tr["primal_obj"], rel=1e-8, abs=1e-10)
+        assert tg["dimacs"] == pytest.approx(tr["dimacs"], rel=1e-4, abs=1e-10)
+    # the fetched dual matrix is the oracle's
+    assert np.linalg.norm(o.solver.X[0] - ref.X[0]) <= 1e-6 * np.linalg.norm(ref.X[0])
+
+
+@pytest.mark.parametrize("name,opts", [("control1", dict(kit=0)), ("tru3", dict(kit=0)), ("vib3", dict(kit=0)),
+                                       ("maxG11", dict(kit=0, datarank=-1)),
+                                       ("theta1", dict(kit=1, preconditioner=1, eDIMACS=1e-6, initpoint=1))])
+def test_resident_equals_host_driver(name, opts):
+    path = os.path.join(GOLD, f"{name}.dat-s")
+    a = _run(path, True, **opts)
+    b = _run(path, False, **opts)
+    assert a.termination_status() == b.termination_status() == "OPTIMAL"
+    assert a.objective_value() == pytest.approx(b.objective_value(), rel=1e-7, abs=1e-9)
+    assert abs(a.solver.iter - b.solver.iter) <= 1
+
+
+def test_thetaG11_resident_pcg():
+    o = _run(os.path.join(GOLD, "thetaG11.dat-s"), True, kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(400.0, rel=1e-4)

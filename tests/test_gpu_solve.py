@@ -13,7 +13,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def _run(path, **opts):
     from loraine_jl_amd.optimizer import Optimizer
-    o = Optimizer()
+    o = Optimizer(resident=False)     # host-NumPy step-length search; resident path: test_gpu_resident.py
     o.set_silent(True)
     for k, v in opts.items():
         o.set_attribute(k, v)

@@ -11,13 +11,13 @@ G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "t
 cases = [("theta1", dict(kit=0, eDIMACS=1e-6, initpoint=1, aamat=2), 0),
          ("maxG11", dict(kit=0, datarank=-1), -1),
          ("thetaG11", dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5), 0)]
-only = sys.argv[1:] 
+only = [a for a in sys.argv[1:] if not a.startswith("--")]
 out = {}
 for name, opts, dr in cases:
     if only and name not in only:
         continue
     path = os.path.join(G, name + ".dat-s")
-    o = Optimizer(); o.set_silent(True)
+    o = Optimizer(resident="--host" not in sys.argv); o.set_silent(True)
     for k, v in opts.items():
         o.set_attribute(k, v)
     o.read_from_file(path)
