@@ -47,18 +47,19 @@ def flops_model(msz, nvar):
 
 def pmc_traffic_bytes():
     """HBM bytes per GEMM1 launch from the committed rocprofv3 --pmc passes (profiles/, same kernel,
-    same 32-matrix launch shape): (FETCH_SIZE + WRITE_SIZE) * 1024.  FETCH_SIZE is left uncorrected:
-    the guide's x2 rule is calibrated for 16 B/lane streams, these loads are 8 B/lane."""
+    same launch shape): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE reports half the
+    bytes of a 16 B/lane stream (MI355X_MICROARCH.md section HBM), which is what the
+    `buffer_load_dwordx4 ... lds` staging of this kernel issues; WRITE_SIZE is exact."""
     import csv
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv"))):
         vals = {}
         for r in csv.DictReader(open(f)):
-            if r["kernel"].endswith("true, false, false, false>(lrn::GemmParams)") and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if "gemm_f64_lds_kernel<false>" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[r["counter"]] = float(r["mean"])
         if len(vals) == 2:
-            best = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+            best = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     return best
 
 
@@ -226,7 +227,7 @@ def main():
                        "msz": msz, "nvar": nvar, "seed": args.seed,
                        "parallelism": "1 GPU" if world == 1 else f"Schur column blocks over {world} GPUs + RCCL all-gather"},
             "algorithmic_tflops": flops_model(msz, nvar) / (ms_per_step * 1e-3) / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128> GEMM1 P_k = A_k W (batched)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_f64_lds_kernel<false> GEMM1 P_k = A_k W (batched, direct-to-LDS staging)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic_bytes() if (msz, world) == (2000, 1) else None,

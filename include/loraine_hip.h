@@ -54,6 +54,10 @@ int lrn_upload_model(lrn_ctx* ctx, int nlmi, int nvar, const int64_t* msizes,
 /* Builder-defined synthetic dense SDP data generated on the device:
  * A_k = (R_k + R_k')/2, R_k iid N(0,1) from a counter-based Philox stream; nlmi = 1. */
 int lrn_synthetic_dense_model(lrn_ctx* ctx, int msz, int nvar, uint64_t seed);
+/* Completes the synthetic data to a strictly feasible SDP: X0 = I + QQ'/msz,
+ * b = AA vec(X0), y0 ~ N(0,1)/sqrt(nvar), S0 = I, C = S0 + mat(AA' y0).  C stays on the device
+ * (resident path); b_out[nvar], y0_out[nvar] and ||C||_F are returned. */
+int lrn_synthetic_dense_problem(lrn_ctx* ctx, uint64_t seed, double* b_out, double* y0_out, double* normC);
 /* dense copy of constraint matrix A_k (0-based k) of block ilmi, msz x msz */
 int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
 /* tuning knobs: "dense_threshold" (nnz above which a branch-1 constraint takes the MFMA

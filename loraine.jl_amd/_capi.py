@@ -26,6 +26,7 @@ SIGNATURES = {
     "lrn_upload_model": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, PPD, PPD, PPD, PPD, PPD, PPD,
                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrn_synthetic_dense_model": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_uint64]),
+    "lrn_synthetic_dense_problem": (C.c_int, [c_ctx, C.c_uint64, C.c_void_p, C.c_void_p, PD]),
     "lrn_get_constraint": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p]),
     "lrn_set_option": (C.c_int, [c_ctx, C.c_char_p, C.c_double]),
     "lrn_set_shard": (C.c_int, [c_ctx, C.c_int, C.c_int]),

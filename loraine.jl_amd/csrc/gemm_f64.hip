@@ -468,7 +468,9 @@ static bool lds_path_ok(const GemmDesc& d) {
   if (d.sAm != 1 || d.sBn != 1 || d.ksplit != 1) return false;
   if (d.sAk < d.M || d.sBk < d.N || (d.sAk & 1) || (d.sBk & 1)) return false;
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || (d.bA & 1) || (d.bB & 1)) return false;
-  if (d.K < 1) return false;
+  // short-K products (Cholesky panel / trailing updates) stay on the generic kernel: the DMA
+  // pipeline needs a long K loop to pay off, and it keeps this kernel's profile = the assembly GEMMs
+  if (d.K < 256) return false;
   // 32-bit byte offsets inside one operand matrix
   if ((double)d.K * (double)d.sAk * 8.0 >= 2.0e9 || (double)d.K * (double)d.sBk * 8.0 >= 2.0e9) return false;
   return true;

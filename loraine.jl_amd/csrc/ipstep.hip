@@ -567,3 +567,63 @@ extern "C" int lrn_dbg_eigmin(lrn_ctx* c, int n, const double* M, double* lam, i
   release(d);
   return rc;
 }
+
+// ---- builder-defined synthetic problem on top of lrn_synthetic_dense_model
+namespace lrn {
+__global__ void synth_x0_kernel(double* __restrict__ X, const double* __restrict__ Q, int n, int r) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    double s = 0.0;
+    for (int k = 0; k < r; ++k) s += Q[i + (long)k * n] * Q[j + (long)k * n];
+    X[e] = s / n + (i == j ? 1.0 : 0.0);
+  }
+}
+__global__ void eye_add_kernel(double* __restrict__ out, const double* __restrict__ M, double sgn, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    out[e] = sgn * M[e] + ((int)(e % n) == (int)(e / n) ? 1.0 : 0.0);
+}
+}  // namespace lrn
+
+extern "C" int lrn_synthetic_dense_problem(lrn_ctx* c, uint64_t seed, double* b_out, double* y0_out, double* normC) {
+  if (!c || c->nlmi != 1 || !b_out || !y0_out) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  LmiBlock& b = c->lmi[0];
+  LRN_TRY(ensure_resident(c, b));
+  const int m = b.msz, n = c->nvar;
+  const long mm_ = (long)m * m;
+  // host-side small random factors (deterministic LCG-free: splitmix64 + Box-Muller)
+  auto next = [&seed]() {
+    seed += 0x9E3779B97F4A7C15ull;
+    uint64_t z = seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto unif = [&]() { return ((double)(next() >> 11) + 0.5) / 9007199254740992.0; };
+  auto gauss = [&]() { return std::sqrt(-2.0 * std::log(unif())) * std::cos(6.283185307179586 * unif()); };
+  const int r = 8;
+  std::vector<double> Q((size_t)m * r), y0(n);
+  for (auto& v : Q) v = gauss();
+  for (auto& v : y0) v = gauss() / std::sqrt((double)n);
+  LRN_TRY(copy_in(c, b.t1.p, Q.data(), Q.size() * 8));
+  hipLaunchKernelGGL(synth_x0_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t0.as<double>(), b.t1.as<double>(), m, r);
+  // b = AA vec(X0)
+  LRN_HIP(c, hipMemsetAsync(c->v1.p, 0, (size_t)n * 8, c->stream));
+  LRN_TRY(aa_times(c, b, b.t0.as<double>(), c->v1.as<double>()));
+  LRN_TRY(copy_out(c, b_out, c->v1.p, (size_t)n * 8));
+  // C = I + mat(AA' y0)
+  LRN_TRY(copy_in(c, c->v0.p, y0.data(), (size_t)n * 8));
+  LRN_TRY(aat_to_mat(c, b, c->v0.as<double>(), b.t0.as<double>()));
+  hipLaunchKernelGGL(eye_add_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.Cd.as<double>(), b.t0.as<double>(), 1.0, m);
+  if (normC) {
+    LRN_TRY(ensure(c, c->redout, 64 * 8));
+    LRN_TRY(dot_dev(c, b.Cd.as<double>(), nullptr, mm_, c->redout.as<double>()));
+    double s = 0;
+    LRN_TRY(copy_out(c, &s, c->redout.p, 8));
+    *normC = std::sqrt(s);
+  }
+  memcpy(y0_out, y0.data(), (size_t)n * 8);
+  return LRN_OK;
+}

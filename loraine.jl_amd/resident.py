@@ -20,9 +20,12 @@ class ResidentSolver(MySolver):
     def setup_solver(self):
         super().setup_solver()
         m = self.model
-        for i in range(m.nlmi):
-            self.dev.ip_set_c(i, m.C[i].toarray())
-        self._normC = [_fro(m.C[i]) for i in range(m.nlmi)]
+        if getattr(m, "on_device", False):          # C was built in HBM (synthetic.py)
+            self._normC = list(m.normC)
+        else:
+            for i in range(m.nlmi):
+                self.dev.ip_set_c(i, m.C[i].toarray())
+            self._normC = [_fro(m.C[i]) for i in range(m.nlmi)]
 
     def initial_point(self):
         super().initial_point()

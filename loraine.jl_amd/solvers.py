@@ -75,9 +75,10 @@ class MySolver:
         self.status = 0
         self.trace = []
         self.dev = device if device is not None else Device(device_index)
-        self.dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes,
-                              B=model.B if len(model.B) else None,
-                              C_lin=model.C_lin if model.nlin else None)        # [GPU] one-time
+        if not getattr(model, "on_device", False):     # synthetic models are generated in HBM
+            self.dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes,
+                                  B=model.B if len(model.B) else None,
+                                  C_lin=model.C_lin if model.nlin else None)    # [GPU] one-time
 
     def _say(self, msg):
         if self.verb > 0:
@@ -442,7 +443,7 @@ class MySolver:
                 gpu_ms=dict(prepare_w=d.timing("prepare_w"), assemble=d.timing("assemble"),
                             factor=d.timing("factor"), solve=d.timing("solve"),
                             prec_setup=d.timing("prec_setup"), pcg=d.timing("pcg"), svd=d.timing("prepw_svd")),
-                svd_sweeps=d.count("svd_sweeps")))
+                svd_sweeps=d.count("svd_sweeps"), find_step_ms=d.timing("find_step")))
             if self.preconditioner == 4:
                 n_ = self.model.n
                 if ((self.cg_iter_cor / 2 > self.erank * self.model.nlmi * math.sqrt(n_) / 20

@@ -43,7 +43,7 @@ def test_gemm_all_layouts(dev, M, N, K, tA, tB):
     assert relerr(C, ref) < 1e-14 * max(8, np.sqrt(K))
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 2048, 64), (2000, 2176, 203), (2050, 2300, 17)])
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (2000, 2176, 403), (2050, 2300, 270)])
 def test_gemm_direct_to_lds_path(dev, M, N, K):
     """NT layout, even leading dimensions, >= 256 tiles: served by gemm_f64_lds_kernel
     (buffer_load ... lds staging; edges and the K tail come from descriptor range checks)."""

@@ -90,3 +90,30 @@ def test_thetaG11_resident_pcg():
     o = _run(os.path.join(GOLD, "thetaG11.dat-s"), True, kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
     assert o.termination_status() == "OPTIMAL"
     assert o.objective_value() == pytest.approx(400.0, rel=1e-4)
+
+
+def test_synthetic_dense_problem_solves_and_matches_oracle(dev):
+    """The builder-defined dense SDP (C4 generator) at a size the CPU oracle can follow:
+    same data (downloaded constraint by constraint), same options -> same optimum."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from loraine_jl_amd.synthetic import synthetic_dense_solver
+    msz, nvar = 40, 60
+    solver, ha = synthetic_dense_solver(dev, msz, nvar, seed=123, options=dict(kit=0, verb=0))
+    # rebuild the same problem for the oracle from the device data
+    A = [[None] + [sp.csc_matrix(dev.get_constraint(0, k)) for k in range(nvar)]]
+    Xd, Sd = dev.ip_get_iterate(0)          # not yet set: just exercises the getter
+    y0 = solver.model.y0
+    Cm = np.eye(msz) - sum(y0[k] * A[0][k + 1].toarray() for k in range(nvar)) * (-1.0) * (-1.0)
+    # C = I + mat(AA' y0) with AA = -A  ->  C = I - sum y0_k A_k
+    Cm = np.eye(msz) - sum(y0[k] * A[0][k + 1].toarray() for k in range(nvar))
+    A[0][0] = sp.csc_matrix(-Cm)            # model.C = -A[.,0]
+    omodel = lo.make_model(A, solver.model.b.copy(), 0.0, None, None)
+    assert np.linalg.norm(Cm) == pytest.approx(solver.model.normC[0], rel=1e-12)
+    ref = lo.MySolver(omodel, dict(kit=0, verb=0))
+    lo.solve(ref)
+    solver.solve(ha)
+    assert solver.status == 1 and ref.status == 1
+    assert solver.primal_obj == pytest.approx(ref.primal_obj, rel=1e-7, abs=1e-9)
+    assert solver.dual_obj == pytest.approx(ref.dual_obj, rel=1e-6, abs=1e-8)
+    assert abs(solver.iter - ref.iter) <= 1

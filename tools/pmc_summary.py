@@ -18,7 +18,7 @@ for d in sorted(glob.glob("gpurun_out/prof_pmc*/")):
             seen.add(key)
             dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for k, cs in agg.items():
-        if "gemm_f64_kernel<128" not in k and "potrf" not in k:
+        if "gemm_f64" not in k and "potrf" not in k:
             continue
         for cname, vals in cs.items():
             rows_out.append(dict(pass_dir=d.rstrip("/").split("/")[-1], kernel=k, counter=cname, dispatches=len(vals),
@@ -35,7 +35,7 @@ def get(kpat, cname):
         if kpat in r["kernel"] and r["counter"] == cname:
             return r
     return None
-k1 = "true, false, false, false>"
+k1 = "gemm_f64_lds_kernel<false>"
 mf, gui = get(k1, "SQ_VALU_MFMA_BUSY_CYCLES"), get(k1, "GRBM_GUI_ACTIVE")
 if mf and gui:
     cyc = gui["mean"] / 8.0
