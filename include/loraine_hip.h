@@ -100,6 +100,9 @@ int lrn_make_rhs(lrn_ctx* ctx, const double* Rp, const double* const* RdS, doubl
 /* ---- CG operator and preconditioners (src/Solvers.jl:572-904) ------------------------- */
 /* Ax = sum AA vec(W mat(AA'x) W) + C_lin((X_lin.*S_lin_inv).*(C_lin'x))   (MyA, :582-614) */
 int lrn_matvec(lrn_ctx* ctx, const double* x, double* Ax);
+/* multi-GPU CG operator: this rank's share  AA[:, idx(R_g)] vec((W M W)[R_g,:])  of the mat-vec,
+ * R_g = row block `rank` of `world` (lrn_set_shard); the caller all-reduces (sum) the nvar-vector. */
+int lrn_matvec_partial(lrn_ctx* ctx, const double* x, double* Ax_partial);
 /* prec: 0 none (MyM_no), 1 H_alpha (Prec_for_CG_tilS_prep :674-809), 2 H_beta
  * (Prec_for_CG_beta :624-663).  info > 0: a Cholesky inside the setup failed. */
 int lrn_prec_setup(lrn_ctx* ctx, int prec, int erank, int aamat, int* info);

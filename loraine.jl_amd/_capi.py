@@ -43,6 +43,7 @@ SIGNATURES = {
     "lrn_schur_import_all": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_make_rhs": (C.c_int, [c_ctx, C.c_void_p, PPD, C.c_void_p]),
     "lrn_matvec": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
+    "lrn_matvec_partial": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     "lrn_prec_setup": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, PI]),
     "lrn_prec_apply": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     "lrn_pcg": (C.c_int, [c_ctx, C.c_void_p, C.c_double, C.c_int, C.c_void_p, PI, PI]),

@@ -81,7 +81,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
 
 int lrn_set_shard(lrn_ctx* c, int rank, int world) {
   if (!c || world < 1 || rank < 0 || rank >= world) return LRN_ERR_ARG;
-  if (world > 1 && !(c->nlmi == 1)) return set_error(c, LRN_ERR_STATE, "column sharding needs nlmi == 1");
+  // the Schur column sharding needs position space (nlmi == 1); the row-sharded CG mat-vec does not
   c->rank = rank;
   c->world = world;
   return LRN_OK;

@@ -117,6 +117,44 @@ __global__ __launch_bounds__(256) void aa_dense_dot_kernel(const double* __restr
   if (threadIdx.x == 0) out[sigma[blockIdx.x]] -= sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// row-sharded variants (multi-GPU mat-vec): only entries with r0 <= row < r1; Zg holds the rows
+// [r0,r1) of Z with leading dimension ldz
+__global__ __launch_bounds__(256) void aa_times_rows_kernel(const long* __restrict__ ptr, const int* __restrict__ er,
+                                                            const int* __restrict__ ec, const double* __restrict__ ev,
+                                                            const double* __restrict__ Zg, int ldz, int r0, int r1,
+                                                            int p_lo, int p_end, const int* __restrict__ sigma,
+                                                            double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = p_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= p_end) return;
+  double s = 0.0;
+  for (long e = ptr[p] + lane; e < ptr[p + 1]; e += 64) {
+    int r = er[e];
+    if (r >= r0 && r < r1) s += ev[e] * Zg[(long)(r - r0) + (long)ec[e] * ldz];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) out[sigma[p]] -= s;
+}
+
+__global__ __launch_bounds__(256) void aa_dense_dot_rows_kernel(const double* __restrict__ Ad, int m,
+                                                                const double* __restrict__ Zg, int ldz, int r0, int r1,
+                                                                const int* __restrict__ sigma, double* __restrict__ out) {
+  __shared__ double sh[4];
+  const double* a = Ad + (long)blockIdx.x * m * m;
+  const int nr = r1 - r0;
+  double s = 0.0;
+  for (long q = threadIdx.x; q < (long)nr * m; q += 256) {
+    int r = (int)(q % nr), cc = (int)(q / nr);
+    s += a[(long)(r0 + r) + (long)cc * m] * Zg[(long)r + (long)cc * ldz];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[sigma[blockIdx.x]] -= sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // linear block: t_l = xs_l * sum_i C[i,l] x_i ; y_i += C[i,l] t_l
 __global__ void lin_matvec_kernel(const long* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
                                   const double* __restrict__ xs, int nlin, const double* __restrict__ x,
@@ -200,6 +238,49 @@ int matvec_dev(lrn_ctx* c, const double* x, double* y) {
     LRN_TRY(aa_times(c, b, c->m2.as<double>(), y));
   }
   if (c->nlin > 0)
+    hipLaunchKernelGGL(lin_matvec_kernel, dim3(nb(c->nlin)), dim3(256), 0, c->stream, c->cl_ptr.as<long>(),
+                       c->cl_rown.as<int>(), c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, x, y);
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
+// Partial mat-vec of rank `rank` of `world`: rows R_g of Z = W M W (row blocks of msz/world),
+// y_g = AA[:, idx(R_g)] vec(Z[R_g,:]); the caller all-reduces y_g over the ranks
+// (one all-reduce of an nvar-vector per mat-vec).  The C_lin term is added by rank 0.
+int matvec_partial_dev(lrn_ctx* c, const double* x, double* y, int rank, int world) {
+  const int n = c->nvar;
+  LRN_HIP(c, hipMemsetAsync(y, 0, (size_t)n * 8, c->stream));
+  for (auto& b : c->lmi) {
+    if (!b.have_W) return set_error(c, LRN_ERR_STATE, "W not set");
+    const int m = b.msz;
+    const int per = (m + world - 1) / world;
+    const int r0 = std::min(m, rank * per), r1 = std::min(m, r0 + per);
+    if (r1 <= r0) continue;
+    const int nr = r1 - r0;
+    LRN_TRY(ensure_m(c, m));
+    double* M = c->m0.as<double>();
+    LRN_TRY(aat_to_mat(c, b, x, M));              // replicated: sparse, cheap
+    GemmDesc g1;                                  // P_g = W[R_g,:] M
+    g1.A = b.W.as<double>() + r0; g1.sAm = 1; g1.sAk = m;
+    g1.B = M; g1.sBk = m; g1.sBn = 1;             // M symmetric
+    g1.C = c->m1.as<double>(); g1.sCm = 1; g1.sCn = nr;
+    g1.M = nr; g1.N = m; g1.K = m;
+    LRN_TRY(gemm(c->stream, g1));
+    GemmDesc g2;                                  // Z_g = P_g W
+    g2.A = c->m1.as<double>(); g2.sAm = 1; g2.sAk = nr;
+    g2.B = b.W.as<double>(); g2.sBk = m; g2.sBn = 1;
+    g2.C = c->m2.as<double>(); g2.sCm = 1; g2.sCn = nr;
+    g2.M = nr; g2.N = m; g2.K = m;
+    LRN_TRY(gemm(c->stream, g2));
+    if (b.npos_nz > b.nd)
+      hipLaunchKernelGGL(aa_times_rows_kernel, dim3((b.npos_nz - b.nd + 3) / 4), dim3(256), 0, c->stream,
+                         b.ent_ptr.as<long>(), b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(),
+                         c->m2.as<double>(), nr, r0, r1, b.nd, b.npos_nz, b.sigma_d.as<int>(), y);
+    if (b.nd > 0)
+      hipLaunchKernelGGL(aa_dense_dot_rows_kernel, dim3(b.nd), dim3(256), 0, c->stream, b.Adense.as<double>(), m,
+                         c->m2.as<double>(), nr, r0, r1, b.sigma_d.as<int>(), y);
+  }
+  if (c->nlin > 0 && rank == 0)
     hipLaunchKernelGGL(lin_matvec_kernel, dim3(nb(c->nlin)), dim3(256), 0, c->stream, c->cl_ptr.as<long>(),
                        c->cl_rown.as<int>(), c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, x, y);
   LRN_HIP(c, hipGetLastError());
@@ -601,6 +682,15 @@ extern "C" int lrn_matvec(lrn_ctx* c, const double* x, double* Ax) {
   LRN_TRY(matvec_dev(c, c->v0.as<double>(), c->v1.as<double>()));
   toc(c, "matvec");
   return copy_out(c, Ax, c->v1.p, (size_t)n * 8);
+}
+
+extern "C" int lrn_matvec_partial(lrn_ctx* c, const double* x, double* Ax_partial) {
+  if (!c || !x || !Ax_partial) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_TRY(copy_in(c, c->v0.p, x, (size_t)n * 8));
+  LRN_TRY(matvec_partial_dev(c, c->v0.as<double>(), c->v1.as<double>(), c->rank, c->world));
+  return copy_out(c, Ax_partial, c->v1.p, (size_t)n * 8);
 }
 
 extern "C" int lrn_make_rhs(lrn_ctx* c, const double* Rp, const double* const* RdS, double* h) {

@@ -393,14 +393,25 @@ static int assemble_rank1(lrn_ctx* c, LmiBlock& b) {
   tic(c);
   hipLaunchKernelGGL(bg_kernel, dim3(n), dim3(256), 0, c->stream, b.b_ptr.as<long>(), b.b_col.as<int>(),
                      b.b_val.as<double>(), b.G.as<double>(), m, c->BG.as<double>());
-  GemmDesc g;
-  g.A = c->BG.as<double>(); g.sAm = m; g.sAk = 1;
-  g.B = c->BG.as<double>(); g.sBk = 1; g.sBn = m;
-  g.C = c->H.as<double>(); g.sCm = 1; g.sCn = n;
-  g.M = g.N = n; g.K = m;
-  g.beta = 1.0;
-  g.flags = GEMM_TRI_LOWER | GEMM_SQUARE;
-  LRN_TRY(gemm(c->stream, g));
+  // owned column blocks of the lower triangle (all of it on one GPU)
+  std::vector<std::pair<int, int>> cols;
+  if (c->world > 1) {
+    for (int c0 = 0; c0 < n; c0 += c->shard_bs)
+      if (shard_owner(c0 / c->shard_bs, c->world) == c->rank) cols.push_back({c0, std::min(n, c0 + c->shard_bs)});
+  } else {
+    cols.push_back({0, n});
+  }
+  for (auto& cb : cols) {
+    const int c0 = cb.first, c1 = cb.second;
+    GemmDesc g;     // H[c0:, c0:c1] += ((BG BG')[c0:, c0:c1]).^2, lower tiles of the sub-block
+    g.A = c->BG.as<double>() + (long)c0 * m; g.sAm = m; g.sAk = 1;
+    g.B = c->BG.as<double>() + (long)c0 * m; g.sBk = 1; g.sBn = m;
+    g.C = c->H.as<double>() + (long)c0 + (long)c0 * n; g.sCm = 1; g.sCn = n;
+    g.M = n - c0; g.N = c1 - c0; g.K = m;
+    g.beta = 1.0;
+    g.flags = GEMM_TRI_LOWER | GEMM_SQUARE;
+    LRN_TRY(gemm(c->stream, g));
+  }
   toc(c, "rank1");
   return LRN_OK;
 }
@@ -408,6 +419,8 @@ static int assemble_rank1(lrn_ctx* c, LmiBlock& b) {
 int schur_assemble(lrn_ctx* c, int mode) {
   const int n = c->nvar;
   if (n <= 0) return set_error(c, LRN_ERR_STATE, "no model uploaded");
+  if (c->world > 1 && !c->pos_space)
+    return set_error(c, LRN_ERR_STATE, "Schur column sharding needs a single LMI block (sigma-position space)");
   hipEvent_t a0, a1;
   if (c->profile) {
     (void)hipEventCreate(&a0);

@@ -87,3 +87,71 @@ class SchurExchange:
         dist.all_gather_into_tensor(self.gathered, self.shard, group=self.group)    # RCCL over xGMI
         torch.cuda.current_stream().synchronize()
         self.dev.schur_import_all(self.gathered)
+
+
+# ------------------------------------------------------------------ kit = 1: sharded PCG
+def pcg_allreduce(matvec_partial, allreduce_sum, precon, b, tol, max_iter, xp=np):
+    """`cg(A, b; tol, maxIter, precon)` (ConjugateGradients.jl 0.1, call sites
+    src/predictor_corrector.jl:134,235) with the operator applied as
+    `allreduce_sum(matvec_partial(p))`: every rank holds all vectors and runs the same
+    iteration; one all-reduce of an nvar-vector per mat-vec is the only exchange.
+    Returns (x, exit_code, iterations)."""
+    x = xp.zeros_like(b)
+    bn = float(xp.linalg.norm(b))
+    if bn == 0.0:
+        return x, 1, 0
+    r = b.clone() if hasattr(b, "clone") else b.copy()
+    res0 = bn
+    if res0 <= tol:
+        return x, 2, 0
+    z = precon(r)
+    p = z.clone() if hasattr(z, "clone") else z.copy()
+    for it in range(1, max_iter + 1):
+        Ap = allreduce_sum(matvec_partial(p))
+        gamma = float(r @ z)
+        pAp = float(p @ Ap)
+        alpha = gamma / pAp if pAp != 0.0 else float("inf")
+        if alpha == float("inf") or alpha < 0 or alpha != alpha:
+            return x, -13, it
+        x += alpha * p
+        r -= alpha * Ap
+        if float(xp.linalg.norm(r)) / res0 <= tol:
+            return x, 30, it
+        z = precon(r)
+        beta = float(z @ r) / gamma
+        p = z + beta * p
+    return x, -2, max_iter
+
+
+class ShardedCG:
+    """Product binding of `pcg_allreduce`: vectors are CUDA tensors, the partial mat-vec and the
+    preconditioner are C-ABI calls on device pointers, the all-reduce is RCCL."""
+
+    def __init__(self, dev, rank, world, group=None):
+        self.dev, self.rank, self.world, self.group = dev, rank, world, group
+        dev.set_shard(rank, world)
+
+    def solve(self, h, tol, max_iter=10000):
+        import torch
+        import torch.distributed as dist
+        from ._capi import ptr
+        dev = self.dev
+        b = torch.as_tensor(np.asarray(h, float)).cuda()
+
+        def mv(p):
+            out = torch.empty_like(p)
+            dev._chk(dev.lib.lrn_matvec_partial(dev.h, ptr(p), ptr(out)), "lrn_matvec_partial")
+            return out
+
+        def ar(v):
+            if self.world > 1:
+                dist.all_reduce(v, group=self.group)
+            return v
+
+        def pc(r):
+            out = torch.empty_like(r)
+            dev._chk(dev.lib.lrn_prec_apply(dev.h, ptr(r), ptr(out)), "lrn_prec_apply")
+            return out
+
+        x, ec, it = pcg_allreduce(mv, ar, pc, b, tol, max_iter, xp=torch)
+        return x.cpu().numpy(), ec, it

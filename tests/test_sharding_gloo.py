@@ -84,3 +84,50 @@ def test_geometry_and_ownership():
     H = np.arange(25.0).reshape(5, 5)
     bufs = np.concatenate([sharding.pack_shard(H, r, 2, 2) for r in range(2)])
     assert np.array_equal(sharding.unpack_all(bufs, 5, 2, 2), H)
+
+
+def _cg_worker(rank, world, port, out_dir):
+    import loraine_jl_amd  # noqa: F401
+    from loraine_jl_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    n = 60
+    Q = rng.standard_normal((n, n))
+    H = Q @ Q.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    d = np.diag(H).copy()
+    rows = np.array_split(np.arange(n), world)[rank]          # this rank's share of the operator
+
+    def mv(p):
+        out = np.zeros(n)
+        out += H[:, rows] @ p[rows]
+        return out
+
+    def ar(v):
+        t = torch.from_numpy(v)
+        dist.all_reduce(t)
+        return t.numpy()
+
+    x, ec, it = sharding.pcg_allreduce(mv, ar, lambda r: r / d, b, 1e-10, 500)
+    # the oracle's cg on the unsharded operator
+    def A(o, v):
+        o[:] = H @ v
+
+    def M(o, v):
+        o[:] = v / d
+    xr, ecr, itr = lo.cg(A, b, tol=1e-10, maxIter=500, precon=M)
+    ok = (ec == ecr == 30) and abs(it - itr) <= 1 and np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    res = torch.tensor([float(ok)], dtype=torch.float64)
+    dist.all_reduce(res)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "cg.npy"), res.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_sharded_pcg(tmp_path):
+    port = _free_port()
+    mp.spawn(_cg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "cg.npy")[0] == 2.0
