@@ -198,3 +198,24 @@ def test_shard_export_import_roundtrip(dev):
         assert relerr(np.tril(sharding.unpack_all(np.concatenate([p.cpu().numpy() for p in parts]), model.n, 2, 16))[:, cols],
                       mine[:, cols]) < 1e-15
     assert relerr(H2, Hfull) < 1e-15
+
+
+def test_rank1_sharded_columns(dev):
+    """datarank=-1 with world=3 column ownership: the union of the shards is the full matrix."""
+    import torch
+    model = lo.model_from_sdpa(os.path.join(GOLD, "maxG11.dat-s"), datarank=-1)
+    W, G = _spd(800, 3)
+    _upload(dev, model)
+    dev.set_scaling(0, W, G)
+    Hfull = dev.schur_assemble(-1, want_H=True)
+    parts = []
+    for r in range(3):
+        dev.set_shard(r, 3)
+        dev.schur_assemble(-1)
+        buf = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
+        dev.schur_export_shard(buf)
+        parts.append(buf)
+    dev.schur_import_all(torch.cat(parts))
+    H2 = dev.schur_get()
+    dev.set_shard(0, 1)
+    assert relerr(H2, Hfull) < 1e-15
