@@ -219,3 +219,23 @@ def test_rank1_sharded_columns(dev):
     H2 = dev.schur_get()
     dev.set_shard(0, 1)
     assert relerr(H2, Hfull) < 1e-15
+
+
+def test_against_committed_golden_iterate(dev):
+    """C-ABI results on the committed golden iterate of theta1 (oracle/make_golden.py): NT scaling,
+    Schur matrix, right-hand side and the Cholesky solve, without running the oracle."""
+    g = np.load(os.path.join(GOLD, "iterates_theta1.npz"))
+    import loraine_jl_amd  # noqa: F401
+    from loraine_jl_amd.model import model_from_sdpa
+    model = model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    info, out = dev.prepare_w(0, g["X"], g["S"])
+    assert info == 0
+    assert relerr(out["W"], g["W"]) < 1e-11
+    assert np.allclose(np.sort(out["D"]), g["D"], rtol=1e-10)
+    H = dev.schur_assemble(0, want_H=True)
+    assert relerr(np.tril(H), g["H_lower"]) < 1e-10
+    h = dev.make_rhs(g["Rp"], [g["Rd"] + g["S"]])
+    assert relerr(h, g["h"]) < 1e-10
+    assert dev.schur_factor() == 0
+    assert relerr(dev.schur_solve(g["h"]), g["dely"]) < 1e-8

@@ -160,3 +160,14 @@ def test_package_host_model_matches_oracle_model():
         assert (a.C_lin != b.C_lin).nnz == 0
         if dr == -1:
             assert (a.B[0] != b.B[0]).nnz == 0
+
+
+def test_golden_iterate_fixture_is_reproducible():
+    """tests/golden/iterates_theta1.npz is what oracle/make_golden.py produces."""
+    g = np.load(os.path.join(GOLD, "iterates_theta1.npz"))
+    model = lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
+    s = lo.MySolver(model, dict(kit=0, eDIMACS=1e-6, initpoint=1, aamat=2, verb=0, maxit=3))
+    lo.solve(s)
+    assert np.allclose(s.X[0], g["X"], rtol=1e-9, atol=1e-12) and np.allclose(s.y, g["y"], rtol=1e-9, atol=1e-12)
+    H = lo.makeBBBBs(model.n, 1, model.A, model.AA, [g["W"]], model.qA, model.sigmaA)
+    assert np.allclose(np.tril(H), g["H_lower"], rtol=1e-10, atol=1e-12)
