@@ -146,6 +146,11 @@ int lrn_ip_update(lrn_ctx* ctx, int predict, const double* alpha, const double* 
 int lrn_ip_stats(lrn_ctx* ctx, double* out5);
 /* smallest eigenvalue of a symmetric n x n matrix (unit test of the Lanczos kernel) */
 int lrn_dbg_eigmin(lrn_ctx* ctx, int n, const double* M, double* lam, int* steps);
+/* k largest eigenpairs (ascending; U_top n x k column-major, may be NULL), smallest eigenvalue and
+ * trace of a symmetric matrix: what the preconditioner setup consumes of `eigen(W)`
+ * (src/Solvers.jl:642-650,706-722); unit test of the Lanczos path (option "prec_eig") */
+int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top, double* U_top,
+                    double* lam_min, double* trace, int* steps);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 /* milliseconds of the named phase in the last call that ran it, measured with HIP events

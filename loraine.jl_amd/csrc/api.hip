@@ -12,6 +12,7 @@ namespace lrn {
 void set_batch_opts(long t, long p);
 void prec_free(lrn_ctx* c);
 extern bool opt_jacobi_warm;
+extern int opt_prec_eig;
 }
 
 extern "C" {
@@ -57,6 +58,7 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->redbuf);
   release(c->redout);
   release(c->lzbuf);
+  release(c->lxbuf);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -72,6 +74,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "profile")) c->profile = value != 0.0;
   else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
+  else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
   else if (!strcmp(key, "jacobi_warm")) lrn::opt_jacobi_warm = value != 0.0;
   else if (!strcmp(key, "shard_bs")) { if (value < 1) return LRN_ERR_ARG; c->shard_bs = (int)value; }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }

@@ -18,6 +18,7 @@
 #include "../../include/loraine_hip.h"
 #include "ctx.h"
 #include "jacobi.h"
+#include "ops.h"
 
 namespace lrn {
 
@@ -445,6 +446,8 @@ __global__ void add_eye_kernel(double* __restrict__ S, int n) {
   if (i < n) S[(long)i * n + i] += 1.0;
 }
 
+int opt_prec_eig = 0;     // 0 auto (Lanczos for msz >= 256), 1 Jacobi eigendecomposition, 2 Lanczos
+
 static double tau_of(const std::vector<double>& lam_s, int aamat) {
   // Solvers.jl:646-650 / :715-719
   double mn = lam_s[0], mean = 0.0;
@@ -474,7 +477,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
   P->ksz = ksz;
   LRN_TRY(ensure(c, P->d, (size_t)n * 8));
   double dsum = 0.0;
-  struct BlkEig { std::vector<int> idx; std::vector<double> coef; double tau; };
+  struct BlkEig { std::vector<int> idx; std::vector<double> coef; double tau; bool lanczos = false; };
   std::vector<BlkEig> be(c->nlmi);
   for (int il = 0; il < c->nlmi; ++il) {
     LmiBlock& b = c->lmi[il];
@@ -484,27 +487,50 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
     size_t mm = (size_t)m * m * 8;
     LRN_TRY(ensure(c, P->E, mm));
     LRN_TRY(ensure(c, P->sig, (size_t)m * 8));
-    LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
-    int sweeps = 0;
-    // eig(W) = svd(G)^2 : columns of E become sigma_j u_j   (Solvers.jl:642,706)
-    LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sweeps));
-    std::vector<double> sg(m);
-    LRN_TRY(copy_out(c, sg.data(), P->sig.p, (size_t)m * 8));
-    std::vector<int> ord(m);
-    for (int i = 0; i < m; ++i) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sg[x] < sg[y]; });   // ascending
-    std::vector<double> lam_s(m - k);
-    for (int i = 0; i < m - k; ++i) lam_s[i] = sg[ord[i]] * sg[ord[i]];
-    double tau = tau_of(lam_s, aamat);
-    be[il].tau = tau;
-    if (aamat < 3) dsum += tau * tau;
+    const bool use_lz = opt_prec_eig == 2 || (opt_prec_eig == 0 && m >= 256);
+    be[il].lanczos = use_lz;
     be[il].idx.resize(k);
     be[il].coef.resize(k);
-    for (int a = 0; a < k; ++a) {
-      int id = ord[m - k + a];
-      double lam = sg[id] * sg[id];
-      be[il].idx[a] = id;
-      be[il].coef[a] = std::sqrt(std::max(lam - tau, 0.0)) / sg[id];   // Umat = v_l sqrt(lambda_l - tau)
+    if (use_lz) {
+      // the setup only consumes the k largest eigenpairs, lambda_min and the mean of the rest
+      // (lanczos.hip): O(steps * msz^2) instead of a full eigendecomposition
+      std::vector<double> lam_top(std::max(1, k));
+      double lam_min = 0.0, tr = 0.0;
+      int steps = 0;
+      LRN_TRY(lanczos_extremes(c, b.W.as<double>(), m, k, lam_top.data(), kind == 1 ? P->E.as<double>() : nullptr,
+                               &lam_min, &tr, &steps));
+      c->counts["prec_lanczos_steps"] = steps;
+      double top = 0.0;
+      for (int a = 0; a < k; ++a) top += lam_top[a];
+      const double mean = (tr - top) / (double)(m - k);
+      const double tau = aamat == 0 ? lam_min : (lam_min + mean) / 2.0 - 1.0e-14;     // Solvers.jl:646-650
+      be[il].tau = tau;
+      if (aamat < 3) dsum += tau * tau;
+      for (int a = 0; a < k; ++a) {
+        be[il].idx[a] = a;                                                  // Ritz vectors are unit columns 0..k-1
+        be[il].coef[a] = std::sqrt(std::max(lam_top[a] - tau, 0.0));
+      }
+    } else {
+      LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
+      int sweeps = 0;
+      // eig(W) = svd(G)^2 : columns of E become sigma_j u_j   (Solvers.jl:642,706)
+      LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sweeps));
+      std::vector<double> sg(m);
+      LRN_TRY(copy_out(c, sg.data(), P->sig.p, (size_t)m * 8));
+      std::vector<int> ord(m);
+      for (int i = 0; i < m; ++i) ord[i] = i;
+      std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sg[x] < sg[y]; });   // ascending
+      std::vector<double> lam_s(m - k);
+      for (int i = 0; i < m - k; ++i) lam_s[i] = sg[ord[i]] * sg[ord[i]];
+      double tau = tau_of(lam_s, aamat);
+      be[il].tau = tau;
+      if (aamat < 3) dsum += tau * tau;
+      for (int a = 0; a < k; ++a) {
+        int id = ord[m - k + a];
+        double lam = sg[id] * sg[id];
+        be[il].idx[a] = id;
+        be[il].coef[a] = std::sqrt(std::max(lam - tau, 0.0)) / sg[id];   // Umat = v_l sqrt(lambda_l - tau)
+      }
     }
     if (kind == 2) continue;
   }
@@ -522,9 +548,15 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
       size_t mm = (size_t)m * m * 8;
       // eigenvectors again (E was overwritten by later blocks only when nlmi > 1)
       if (c->nlmi > 1) {
-        LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
-        int sw = 0;
-        LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sw));
+        if (be[il].lanczos) {
+          std::vector<double> lt(std::max(1, k));
+          double lmn, trc;
+          LRN_TRY(lanczos_extremes(c, b.W.as<double>(), m, k, lt.data(), P->E.as<double>(), &lmn, &trc, nullptr));
+        } else {
+          LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
+          int sw = 0;
+          LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sw));
+        }
       }
       LRN_TRY(ensure(c, P->Um, (size_t)m * k * 8 + (size_t)k * 16));
       double* Um = P->Um.as<double>();

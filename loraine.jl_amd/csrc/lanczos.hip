@@ -1,0 +1,335 @@
+// Extreme eigenpairs of a dense symmetric matrix by Lanczos with full re-orthogonalisation.
+//
+// The preconditioner setup of the reference calls a FULL `eigen(W)` (src/Solvers.jl:642,706) but
+// consumes only: the k largest eigenpairs (Umat = V_l sqrt(Lambda_l - tau I), :710-722), the
+// smallest eigenvalue and the mean of the remaining ones (tau, :646-650,:715-719).  With
+// W0 = W - Umat Umat'  nothing else of the decomposition is needed, so for
+// large msz the O(25 msz^3) eigensolver is replaced by m << msz Lanczos steps: each step is one
+// bandwidth-bound symmetric mat-vec on all CUs plus re-orthogonalisation GEMVs against the basis.
+// mean(lambda_s) comes from trace(W) - sum of the k largest.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "ops.h"
+
+namespace lrn {
+
+__global__ void lx_init_kernel(double* __restrict__ q, int n, unsigned salt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = ((unsigned)i + salt * 40503u) * 2246822519u + 374761393u;
+  h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  q[i] = ((double)h / 4294967296.0) - 0.5;
+}
+
+__global__ __launch_bounds__(256) void lx_symv_part_kernel(const double* __restrict__ M, int n, int cper,
+                                                           const double* __restrict__ q, double* __restrict__ ypart) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int c0 = blockIdx.y * cper, c1 = min(n, c0 + cper);
+  double s = 0.0;
+  for (int j = c0; j < c1; ++j) s += M[(long)i + (long)j * n] * q[j];
+  ypart[(long)blockIdx.y * n + i] = s;
+}
+
+__device__ __forceinline__ double lx_wg_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < 16; ++i) s += sh[i];
+  return s;
+}
+
+// w = sum ypart ; alpha = q_j . w ; w -= alpha q_j + beta_prev q_{j-1}
+__global__ __launch_bounds__(1024) void lx_alpha_kernel(const double* __restrict__ ypart, int nchunk, int n, int j,
+                                                        const double* __restrict__ Q, double* __restrict__ w,
+                                                        double* __restrict__ ab) {
+  __shared__ double sh[16];
+  const int t = threadIdx.x;
+  const double* q = Q + (long)j * n;
+  const double* qp = j > 0 ? Q + (long)(j - 1) * n : nullptr;
+  const double bprev = j > 0 ? ab[2 * (j - 1) + 1] : 0.0;
+  double a = 0.0;
+  for (int i = t; i < n; i += 1024) {
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += ypart[(long)k * n + i];
+    w[i] = s;
+    a += q[i] * s;
+  }
+  a = lx_wg_sum(a, sh);
+  for (int i = t; i < n; i += 1024) w[i] -= a * q[i] + (qp ? bprev * qp[i] : 0.0);
+  if (t == 0) ab[2 * j] = a;
+}
+
+// c[col] = Q[:,col] . w   (one workgroup per basis vector)
+__global__ __launch_bounds__(256) void lx_qtw_kernel(const double* __restrict__ Q, int n, const double* __restrict__ w,
+                                                     double* __restrict__ cvec) {
+  __shared__ double sh[4];
+  const double* col = Q + (long)blockIdx.x * n;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += col[i] * w[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) cvec[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// w -= Q[:, 0..nc) c
+__global__ void lx_sub_kernel(const double* __restrict__ Q, int n, int nc, const double* __restrict__ cvec,
+                              double* __restrict__ w) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int cidx = 0; cidx < nc; ++cidx) s += Q[(long)i + (long)cidx * n] * cvec[cidx];
+  w[i] -= s;
+}
+
+// beta_j = ||w|| ; Q[:, j+1] = w / beta_j        (j == -1: normalise Q[:,0] in place)
+__global__ __launch_bounds__(1024) void lx_norm_kernel(double* __restrict__ Q, int n, int j, const double* __restrict__ w,
+                                                       double* __restrict__ ab) {
+  __shared__ double sh[16];
+  const int t = threadIdx.x;
+  const double* src = j < 0 ? Q : w;
+  double* dst = Q + (long)(j + 1) * n;
+  double s = 0.0;
+  for (int i = t; i < n; i += 1024) s += src[i] * src[i];
+  s = lx_wg_sum(s, sh);
+  double b = sqrt(s);
+  double r = b > 0.0 ? 1.0 / b : 0.0;
+  for (int i = t; i < n; i += 1024) dst[i] = src[i] * r;
+  if (t == 0 && j >= 0) ab[2 * j + 1] = b;
+}
+
+__global__ __launch_bounds__(256) void lx_trace_kernel(const double* __restrict__ M, int n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += M[(long)i * n + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---- host-side tridiagonal helpers
+static int sturm_below(const std::vector<double>& a, const std::vector<double>& b, int m, double x) {
+  int cnt = 0;
+  double d = 1.0;
+  for (int i = 0; i < m; ++i) {
+    double bb = i > 0 ? b[i - 1] * b[i - 1] : 0.0;
+    d = a[i] - x - (i > 0 ? bb / d : 0.0);
+    if (d == 0.0) d = -1e-300;
+    if (d < 0.0) ++cnt;
+  }
+  return cnt;
+}
+
+// idx-th smallest eigenvalue (0-based) of the tridiagonal matrix by bisection
+static double tri_eig_by_index(const std::vector<double>& a, const std::vector<double>& b, int m, int idx) {
+  double lo = a[0], hi = a[0];
+  for (int i = 0; i < m; ++i) {
+    double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < m - 1 ? std::fabs(b[i]) : 0.0);
+    lo = std::min(lo, a[i] - r);
+    hi = std::max(hi, a[i] + r);
+  }
+  for (int it = 0; it < 200; ++it) {
+    double mid = 0.5 * (lo + hi);
+    if (mid == lo || mid == hi) break;
+    if (sturm_below(a, b, m, mid) >= idx + 1) hi = mid; else lo = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+// eigenvector of T for eigenvalue theta by inverse iteration; (T - shift I) is factored with
+// partial pivoting (the LAPACK dgttrf / dgtts2 recurrences); returns a unit vector s
+static void tri_eigvec(const std::vector<double>& a, const std::vector<double>& b, int m, double theta,
+                       std::vector<double>& s, int salt) {
+  s.assign(m, 0.0);
+  if (m == 1) { s[0] = 1.0; return; }
+  double scale = 0.0;
+  for (int i = 0; i < m; ++i) scale = std::max(scale, std::fabs(a[i]) + (i < m - 1 ? std::fabs(b[i]) : 0.0));
+  const double tiny = 1e-300 + 1e-17 * scale;
+  const double shift = theta + (2 + salt) * 1e-14 * scale;     // keeps the matrix non-singular
+  std::vector<double> dl(m - 1), d(m), du(m - 1), du2(std::max(0, m - 2), 0.0);
+  std::vector<int> ip(m - 1, 0);
+  for (int i = 0; i < m; ++i) d[i] = a[i] - shift;
+  for (int i = 0; i < m - 1; ++i) { dl[i] = b[i]; du[i] = b[i]; }
+  for (int i = 0; i < m - 1; ++i) {
+    const bool last = (i == m - 2);
+    if (std::fabs(d[i]) >= std::fabs(dl[i])) {
+      ip[i] = 0;
+      if (d[i] == 0.0) d[i] = tiny;
+      double f = dl[i] / d[i];
+      dl[i] = f;
+      d[i + 1] -= f * du[i];
+      if (!last) du2[i] = 0.0;
+    } else {
+      ip[i] = 1;
+      double f = d[i] / dl[i];
+      d[i] = dl[i];
+      dl[i] = f;
+      double tmp = du[i];
+      du[i] = d[i + 1];
+      d[i + 1] = tmp - f * d[i + 1];
+      if (!last) { du2[i] = du[i + 1]; du[i + 1] = -f * du[i + 1]; }
+    }
+  }
+  if (d[m - 1] == 0.0) d[m - 1] = tiny;
+  std::vector<double> x(m);
+  for (int i = 0; i < m; ++i) x[i] = 1.0 + 0.013 * ((i * 7 + salt * 3) % 11);
+  for (int it = 0; it < 4; ++it) {
+    for (int i = 0; i < m - 1; ++i) {
+      if (!ip[i]) x[i + 1] -= dl[i] * x[i];
+      else { double tmp = x[i]; x[i] = x[i + 1]; x[i + 1] = tmp - dl[i] * x[i]; }
+    }
+    x[m - 1] /= d[m - 1];
+    x[m - 2] = (x[m - 2] - du[m - 2] * x[m - 1]) / d[m - 2];
+    for (int i = m - 3; i >= 0; --i) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
+    double nrm = 0.0;
+    for (double v : x) nrm += v * v;
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0.0) || !std::isfinite(nrm)) break;
+    for (int i = 0; i < m; ++i) x[i] /= nrm;
+  }
+  s = x;
+}
+
+// k largest eigenpairs + smallest eigenvalue + trace of the symmetric n x n matrix M (device).
+// lam_top[k] ascending (like F.values[n-k+1:n]); U_top (device, n x k, unit columns) may be null.
+int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
+                     double* trace, int* steps_out) {
+  hipStream_t st = c->stream;
+  if (k < 0 || k >= n) return set_error(c, LRN_ERR_ARG, "lanczos_extremes: bad k");
+  const int mmax = std::min(n, std::max(4 * k + 120, 160));
+  int nchunk = std::max(1, std::min(64, (int)(512 / std::max(1, (n + 255) / 256))));
+  nchunk = std::min(nchunk, std::max(1, n / 16));
+  const int cper = (n + nchunk - 1) / nchunk;
+  nchunk = (n + cper - 1) / cper;
+  LRN_TRY(ensure(c, c->lxbuf, ((size_t)(mmax + 2) * n + (size_t)nchunk * n + 4 * (size_t)mmax + (size_t)mmax * (k + 1) + 128) * 8));
+  double* Q = c->lxbuf.as<double>();
+  double* w = Q + (size_t)(mmax + 1) * n;
+  double* ypart = w + n;
+  double* ab = ypart + (size_t)nchunk * n;
+  double* cvec = ab + 2 * (size_t)mmax + 8;
+  double* Sdev = cvec + mmax + 8;
+  hipLaunchKernelGGL(lx_trace_kernel, dim3(1), dim3(256), 0, st, M, n, cvec);
+  double tr = 0.0;
+  LRN_TRY(copy_out(c, &tr, cvec, 8));
+  if (trace) *trace = tr;
+  hipLaunchKernelGGL(lx_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Q, n, 0u);
+  hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, Q, n, -1, Q, ab);
+  std::vector<double> a, b, hab;
+  std::vector<std::vector<double>> svec(k + 1);
+  std::vector<double> th(k + 1, 0.0);
+  int m = 0;
+  const int batch = 20;
+  bool done = false;
+  std::vector<char> cut(mmax + 1, 0);
+  for (int guard = 0; !done && m < mmax && guard < 2 * mmax + 8; ++guard) {
+    const int m1 = std::min(mmax, m + batch);
+    for (int j = m; j < m1; ++j) {
+      hipLaunchKernelGGL(lx_symv_part_kernel, dim3((n + 255) / 256, nchunk), dim3(256), 0, st, M, n, cper, Q + (size_t)j * n, ypart);
+      hipLaunchKernelGGL(lx_alpha_kernel, dim3(1), dim3(1024), 0, st, ypart, nchunk, n, j, Q, w, ab);
+      for (int pass = 0; pass < 2; ++pass) {          // classical Gram-Schmidt, twice
+        hipLaunchKernelGGL(lx_qtw_kernel, dim3(j + 1), dim3(256), 0, st, Q, n, w, cvec);
+        hipLaunchKernelGGL(lx_sub_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Q, n, j + 1, cvec, w);
+      }
+      hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, Q, n, j, w, ab);
+    }
+    m = m1;
+    hab.resize(2 * (size_t)m);
+    LRN_TRY(copy_out(c, hab.data(), ab, (size_t)2 * m * 8));
+    a.resize(m); b.resize(m);
+    double scale = 0.0;
+    int mm_ = m;
+    bool broke = false;      // invariant subspace reached: beta_j = 0 (e.g. W = c I at the initial point)
+    for (int j = 0; j < m; ++j) {
+      a[j] = hab[2 * j]; b[j] = hab[2 * j + 1];
+      scale = std::max(scale, std::fabs(a[j]) + std::fabs(b[j]));
+      if (j < (int)cut.size() && cut[j]) { b[j] = 0.0; continue; }        // an earlier restart point
+      if (!(b[j] > 1e-13 * scale)) { mm_ = j + 1; broke = true; b[j] = 0.0; break; }
+    }
+    m = mm_;
+    if (m > k) {
+      // wanted Ritz pairs: k largest (ascending order), then the smallest
+      double worst = 0.0;
+      for (int i = 0; i < k; ++i) {
+        th[i] = tri_eig_by_index(a, b, m, m - k + i);
+        tri_eigvec(a, b, m, th[i], svec[i], i);
+        worst = std::max(worst, std::fabs(b[m - 1] * svec[i][m - 1]) / std::max(std::fabs(th[i]), 1e-300));
+      }
+      th[k] = tri_eig_by_index(a, b, m, 0);
+      tri_eigvec(a, b, m, th[k], svec[k], k);
+      // lambda_min only enters tau = (lambda_min + mean)/2: converge it relative to the mean
+      double top = 0.0;
+      for (int i = 0; i < k; ++i) top += th[i];
+      const double mean = std::fabs(tr - top) / (double)(n - k);
+      const double rmin = std::fabs(b[m - 1] * svec[k][m - 1]);
+      done = (worst <= 1e-10 && rmin <= 1e-6 * std::max(std::fabs(th[k]), mean)) || m >= n;
+    }
+    if (!done && broke && m < mmax) {
+      // restart inside the orthogonal complement: T becomes block diagonal (beta = 0 between blocks)
+      cut[m - 1] = 1;
+      LRN_HIP(c, hipMemsetAsync(ab + 2 * (size_t)(m - 1) + 1, 0, 8, st));
+      hipLaunchKernelGGL(lx_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, n, (unsigned)m);
+      for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(lx_qtw_kernel, dim3(m), dim3(256), 0, st, Q, n, w, cvec);
+        hipLaunchKernelGGL(lx_sub_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Q, n, m, cvec, w);
+      }
+      hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, Q, n, m - 1, w, ab);
+      LRN_HIP(c, hipMemsetAsync(ab + 2 * (size_t)(m - 1) + 1, 0, 8, st));
+    }
+  }
+  if (m <= k) return set_error(c, LRN_ERR_STATE, "lanczos_extremes: Krylov space smaller than erank");
+  for (int i = 0; i < k; ++i) lam_top[i] = th[i];
+  if (lam_min) *lam_min = th[k];
+  if (steps_out) *steps_out = m;
+  if (U_top && k > 0) {
+    // orthonormalise the small eigenvectors among themselves (clustered top eigenvalues)
+    for (int i = 0; i < k; ++i) {
+      for (int p = 0; p < i; ++p) {
+        double d = 0.0;
+        for (int r = 0; r < m; ++r) d += svec[i][r] * svec[p][r];
+        for (int r = 0; r < m; ++r) svec[i][r] -= d * svec[p][r];
+      }
+      double nrm = 0.0;
+      for (int r = 0; r < m; ++r) nrm += svec[i][r] * svec[i][r];
+      nrm = std::sqrt(nrm);
+      for (int r = 0; r < m; ++r) svec[i][r] /= nrm;
+    }
+    std::vector<double> Sh((size_t)m * k);
+    for (int i = 0; i < k; ++i)
+      for (int r = 0; r < m; ++r) Sh[(size_t)r + (size_t)i * m] = svec[i][r];
+    LRN_TRY(copy_in(c, Sdev, Sh.data(), Sh.size() * 8));
+    GemmDesc g;      // U = Q[:, 0..m) S
+    g.A = Q; g.sAm = 1; g.sAk = n;
+    g.B = Sdev; g.sBk = 1; g.sBn = m;
+    g.C = U_top; g.sCm = 1; g.sCn = n;
+    g.M = n; g.N = k; g.K = m;
+    LRN_TRY(gemm(st, g));
+  }
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
+}  // namespace lrn
+
+extern "C" int lrn_dbg_lanczos(lrn_ctx* c, int n, int k, const double* M, double* lam_top, double* U_top,
+                               double* lam_min, double* trace, int* steps) {
+  if (!c || n <= 0 || !M || !lam_top) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  lrn::DBuf d, u;
+  LRN_TRY(lrn::ensure(c, d, (size_t)n * n * 8));
+  LRN_TRY(lrn::ensure(c, u, (size_t)n * std::max(1, k) * 8));
+  LRN_TRY(lrn::copy_in(c, d.p, M, (size_t)n * n * 8));
+  int rc = lrn::lanczos_extremes(c, d.as<double>(), n, k, lam_top, U_top ? u.as<double>() : nullptr, lam_min, trace, steps);
+  if (rc == LRN_OK && U_top && k > 0) rc = lrn::copy_out(c, U_top, u.p, (size_t)n * k * 8);
+  lrn::release(d);
+  lrn::release(u);
+  return rc;
+}

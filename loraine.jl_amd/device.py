@@ -327,6 +327,15 @@ class Device:
         self._chk(self.lib.lrn_ip_stats(self.h, ptr(out)), "lrn_ip_stats")
         return out[:5 * nl].reshape(nl, 5)
 
+    def dbg_lanczos(self, M, k, vectors=True):
+        M = f64(M)
+        n = M.shape[0]
+        lam = np.zeros(max(k, 1)); U = np.zeros((n, max(k, 1)), order="F")
+        lmin = C.c_double(0.0); tr = C.c_double(0.0); st = C.c_int(0)
+        self._chk(self.lib.lrn_dbg_lanczos(self.h, n, int(k), ptr(M), ptr(lam), ptr(U) if vectors else None,
+                                           C.byref(lmin), C.byref(tr), C.byref(st)), "lrn_dbg_lanczos")
+        return lam[:k], U[:, :k], lmin.value, tr.value, st.value
+
     def dbg_eigmin(self, M):
         M = f64(M)
         lam = C.c_double(0.0); st = C.c_int(0)

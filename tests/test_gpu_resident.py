@@ -86,10 +86,17 @@ def test_resident_equals_host_driver(name, opts):
     assert abs(a.solver.iter - b.solver.iter) <= 1
 
 
-def test_thetaG11_resident_pcg():
-    o = _run(os.path.join(GOLD, "thetaG11.dat-s"), True, kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
+@pytest.mark.parametrize("eig", [1, 2])
+def test_thetaG11_resident_pcg(dev, eig):
+    # prec_eig 1: eig(W) by Jacobi (the reference's full `eigen`); 2: Lanczos extremes only
+    dev.set_option("prec_eig", eig)
+    try:
+        o = _run(os.path.join(GOLD, "thetaG11.dat-s"), True, kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
+    finally:
+        dev.set_option("prec_eig", 0)
     assert o.termination_status() == "OPTIMAL"
     assert o.objective_value() == pytest.approx(400.0, rel=1e-4)
+    print(f"prec_eig={eig}: iter={o.solver.iter} cg_iter={o.solver.cg_iter_tot} time={o.solver.tottime:.2f}s")
 
 
 def test_synthetic_dense_problem_solves_and_matches_oracle(dev):

@@ -122,8 +122,48 @@ def test_make_rhs_matches_oracle(dev):
     assert relerr(h, href) < 1e-12
 
 
-@pytest.mark.parametrize("prec,erank", [(0, 1), (2, 1), (1, 1), (1, 3)])
-def test_preconditioner_apply_and_pcg(dev, prec, erank):
+@pytest.mark.parametrize("n,k", [(40, 3), (600, 1), (600, 5), (1800, 2)])
+def test_lanczos_extremes(dev, n, k):
+    """What prec_setup consumes of eigen(W) (Solvers.jl:642-650,706-722): k largest pairs,
+    lambda_min, trace -- on a spectrum shaped like W late in an IP run."""
+    rng = np.random.default_rng(n + k)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.exp(rng.uniform(np.log(1e-3), np.log(1.0), n))
+    lam[-6:] = [30.0, 80.0, 200.0, 900.0, 4000.0, 2.0e4]
+    W = (Q * lam) @ Q.T
+    W = 0.5 * (W + W.T)
+    ev, V = np.linalg.eigh(W)
+    lt, U, lmin, tr, steps = dev.dbg_lanczos(W, k)
+    assert steps <= n
+    assert np.allclose(lt, ev[-k:], rtol=1e-9)
+    assert abs(tr - np.trace(W)) <= 1e-11 * abs(np.trace(W))
+    # Ritz value from above; its accuracy is absolute in ||W||, which is all tau needs (:646-650)
+    assert ev[0] - 1e-9 * ev[-1] <= lmin <= ev[0] + (1e-12 if n == steps else 5e-2)
+    assert np.allclose(np.abs(np.sum(U * V[:, -k:], axis=0)), 1.0, atol=1e-8)
+    assert np.allclose(U.T @ U, np.eye(k), atol=1e-10)
+
+
+def test_lanczos_invariant_subspace_restart(dev):
+    """W = c I at the initial point (Solvers.jl:448-460): every Krylov space is 1-dimensional."""
+    lt, U, lmin, tr, steps = dev.dbg_lanczos(3.0 * np.eye(50), 2)
+    assert np.allclose(lt, 3.0) and lmin == pytest.approx(3.0) and tr == pytest.approx(150.0)
+    assert np.allclose(U.T @ U, np.eye(2), atol=1e-12)
+    W = np.diag([2.0] * 30 + [7.0, 11.0])           # three distinct eigenvalues, k = 2
+    lt, U, lmin, tr, steps = dev.dbg_lanczos(W, 2)
+    assert np.allclose(lt, [7.0, 11.0]) and lmin == pytest.approx(2.0)
+    assert np.allclose(np.abs(U[30, 0]), 1.0) and np.allclose(np.abs(U[31, 1]), 1.0)
+
+
+@pytest.mark.parametrize("prec,erank,eig", [(0, 1, 1), (2, 1, 1), (1, 1, 1), (1, 3, 1), (2, 1, 2), (1, 1, 2), (1, 3, 2)])
+def test_preconditioner_apply_and_pcg(dev, prec, erank, eig):
+    dev.set_option("prec_eig", eig)        # 1: Jacobi eigendecomposition, 2: Lanczos extremes
+    try:
+        _preconditioner_apply_and_pcg(dev, prec, erank, 1e-9 if eig == 1 else 1e-7)
+    finally:
+        dev.set_option("prec_eig", 0)
+
+
+def _preconditioner_apply_and_pcg(dev, prec, erank, tol_apply):
     model = lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
     s = _iterate(model, dict(kit=1, preconditioner=max(prec, 1) if prec else 0, erank=erank), 6)
     X, S = s.X[0], s.S[0]
@@ -148,7 +188,7 @@ def test_preconditioner_apply_and_pcg(dev, prec, erank):
     ref = np.zeros(model.n)
     Mo(ref, x)
     got = dev.prec_apply(x)
-    assert relerr(got, ref) < 1e-9
+    assert relerr(got, ref) < tol_apply
     # PCG against the oracle's cg on the same operator
     h = rng.standard_normal(model.n)
     Ao = lo.MyA(s.W, model.AA, 0, model.C_lin, s.X_lin, s.S_lin_inv)
