@@ -140,7 +140,14 @@ def main():
     backend = os.environ.get("LRN_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("LRN_BENCH_ONE_GPU") else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # LRN_BENCH_DIST1=1: take the sharded path (process group, export, all-gather, import) with
+    # world_size 1 -- exercises RCCL and the device-pointer exchange on a one-GPU box
+    sharded = world > 1 or bool(os.environ.get("LRN_BENCH_DIST1"))
+    if sharded and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -158,7 +165,7 @@ def main():
     h_pred = torch.from_numpy(rng.standard_normal(nvar)).cuda()
     h_corr = torch.from_numpy(rng.standard_normal(nvar)).cuda()
     dely = torch.zeros(nvar, dtype=torch.float64, device="cuda")
-    if world > 1:
+    if sharded:
         dev.set_shard(rank, world)
         shard = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
         gathered = torch.zeros(dev.shard_doubles() * world, dtype=torch.float64, device="cuda")
@@ -167,7 +174,7 @@ def main():
 
     def step():
         dev.schur_assemble(0)                                   # makeBBBBs on the owned columns
-        if world > 1:
+        if sharded:
             dev.schur_export_shard(shard)
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered, shard)    # RCCL over xGMI
@@ -184,7 +191,7 @@ def main():
         dev._chk(lib.lrn_schur_solve(dev.h, ptr(h_corr), ptr(dely)), "solve")   # corrector
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -200,7 +207,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
+    if sharded:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -209,8 +216,8 @@ def main():
         # dominant kernel: GEMM1  P_k = A_k W  (gemm_f64_kernel<128,128,...>, batched)
         n1 = max(1, dev.count("gemm1"))
         t1 = dev.timing("gemm1") / n1                               # ms per launch (HIP events)
-        nown = nvar if world == 1 else sum(min(nvar, (b + 1) * 128) - b * 128
-                                           for b in range((nvar + 127) // 128) if b % world == rank)
+        from loraine_jl_amd.sharding import owned_columns
+        nown = len(owned_columns(nvar, rank, world))
         launches_per_step = n1 / args.steps
         units_per_launch = nown / launches_per_step                 # constraint matrices per launch
         alg_flops_launch = 2.0 * msz ** 3 * units_per_launch
@@ -240,7 +247,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7)
         # correctness guard for the sharded path: the solve must satisfy H x = h on the full matrix
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
