@@ -60,8 +60,11 @@ int lrn_synthetic_dense_model(lrn_ctx* ctx, int msz, int nvar, uint64_t seed);
 int lrn_synthetic_dense_problem(lrn_ctx* ctx, uint64_t seed, double* b_out, double* y0_out, double* normC);
 /* dense copy of constraint matrix A_k (0-based k) of block ilmi, msz x msz */
 int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
-/* tuning knobs: "dense_threshold" (nnz above which a branch-1 constraint takes the MFMA
- * path), "profile" (0/1), "t_batch", "p_batch". */
+/* tuning knobs (process-wide): "dense_threshold" (nnz above which a branch-1 constraint takes
+ * the MFMA path), "profile" (0/1), "t_batch", "p_batch", "shard_bs", "jacobi_warm" (0/1),
+ * "prec_eig" (0 auto / 1 full Jacobi eigendecomposition / 2 Lanczos extremes in lrn_prec_setup),
+ * "matvec_sparse" (0 auto / 1 dense GEMM mat-vec / 2 pattern-restricted mat-vec when every
+ * constraint is sparse), "reset_timing". */
 int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
 /* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */
 int lrn_set_shard(lrn_ctx* ctx, int rank, int world);

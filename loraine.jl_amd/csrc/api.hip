@@ -13,6 +13,7 @@ void set_batch_opts(long t, long p);
 void prec_free(lrn_ctx* c);
 extern bool opt_jacobi_warm;
 extern int opt_prec_eig;
+extern int opt_matvec_sparse;
 }
 
 extern "C" {
@@ -75,6 +76,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
+  else if (!strcmp(key, "matvec_sparse")) lrn::opt_matvec_sparse = (int)value;
   else if (!strcmp(key, "jacobi_warm")) lrn::opt_jacobi_warm = value != 0.0;
   else if (!strcmp(key, "shard_bs")) { if (value < 1) return LRN_ERR_ARG; c->shard_bs = (int)value; }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }

@@ -175,6 +175,139 @@ __global__ void lin_diag_kernel(const long* __restrict__ ptr, const int* __restr
   for (long k = ptr[l]; k < ptr[l + 1]; ++k) atomicAdd(&d[row[k]], val[k] * val[k] * xs[l]);
 }
 
+
+// ------------------------------------------------------------------ sparse-aware mat-vec
+// When M = mat(AA'x) is sparse (every constraint sparse, e.g. C5: 9 nnz each, 18 per column of M),
+// AA vec(W M W) needs Z = W M W only on the pattern of M.  With N = M W  (N(:,q) = M W(:,q)):
+//   Z[p,q] = W(:,p) . N(:,q)        -- two contiguous columns
+// and N' = W M is a sparse combination of columns of W:  N'(:,r) = sum_s M[s,r] W(:,s).
+// 2 nnz(M) msz + nnz(M) msz flop instead of 4 msz^3; the kernels are bandwidth-bound (L2 / MALL).
+int opt_matvec_sparse = 0;      // 0 auto, 1 dense GEMM path, 2 sparse path whenever the pattern allows
+
+__global__ __launch_bounds__(256) void sp_gather_kernel(const long* __restrict__ cq_ptr, const int* __restrict__ cq_j,
+                                                        const double* __restrict__ cq_v, long ncq,
+                                                        const double* __restrict__ x, double* __restrict__ raw) {
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ncq) return;
+  double s = 0.0;
+  for (long k = cq_ptr[t] + lane; k < cq_ptr[t + 1]; k += 64) s += cq_v[k] * x[cq_j[k]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) raw[t] = s;
+}
+
+// mat(): (M + M')/2 on the pattern  (kron_etc.jl:13-18)
+__global__ void sp_symmetrize_kernel(const double* __restrict__ raw, const int* __restrict__ pc_t, long ncq,
+                                     double* __restrict__ Mv) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ncq) Mv[t] = (raw[t] + raw[pc_t[t]]) / 2.0;
+}
+
+// N[r, q] = sum_{t in column r of M} Mv[t] * W[q, row(t)]   for q in [q_lo, q_hi), all r.
+// One thread per q, 16 consecutive r per workgroup: W is read along q (coalesced 2 KB per stored
+// entry), N is written as 128 contiguous bytes per thread.  blockIdx.x walks r (fast) so that the
+// 256 rows of W a q-tile touches (msz * 2 KB) stay in L2 / MALL across the r-tiles.
+__global__ __launch_bounds__(256) void sp_wm_kernel(const long* __restrict__ pc_ptr, const int* __restrict__ pc_r,
+                                                    const double* __restrict__ Mv, const double* __restrict__ W, int m,
+                                                    int q_lo, int q_hi, double* __restrict__ N) {
+  const int q = q_lo + blockIdx.y * 256 + threadIdx.x;
+  const int r0 = blockIdx.x * 16;
+  const bool live = q < q_hi;
+  const double* wq = W + (live ? q : q_lo);
+  double acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + i;
+    if (r < m) {
+      const long t1 = pc_ptr[r + 1];
+      for (long t = pc_ptr[r]; t < t1; ++t) acc[i] += Mv[t] * wq[(long)pc_r[t] * m];
+    }
+  }
+  if (!live) return;
+  double* dst = N + (long)q * m + r0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (r0 + i < m) dst[i] = acc[i];
+}
+
+// Zs[t] = W(:,p_t) . N(:,q_t) for the stored entries of pattern column q (one workgroup per column);
+// mirror: only p <= q is computed and copied to the transposed entry (Z is symmetric).
+__global__ __launch_bounds__(256) void sp_dot_kernel(const long* __restrict__ pc_ptr, const int* __restrict__ pc_r,
+                                                     const int* __restrict__ pc_t, const double* __restrict__ W,
+                                                     const double* __restrict__ N, int m, int q_lo, int mirror,
+                                                     double* __restrict__ Zs) {
+  __shared__ double sh[4];
+  const int q = q_lo + blockIdx.x;
+  const double* nq = N + (long)q * m;
+  const long t1 = pc_ptr[q + 1];
+  for (long t = pc_ptr[q]; t < t1; ++t) {
+    const int p = pc_r[t];
+    if (mirror && p > q) break;                 // rows ascending within a column
+    const double* wp = W + (long)p * m;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) s += wp[i] * nq[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = sh[0] + sh[1] + sh[2] + sh[3];
+      Zs[t] = v;
+      if (mirror && p != q) Zs[pc_t[t]] = v;
+    }
+  }
+}
+
+// out[sigma[p]] -= sum_e a_e Zs[ent_t[e]]   (entries with column in [c_lo, c_hi))
+__global__ __launch_bounds__(256) void sp_aa_times_kernel(const long* __restrict__ ptr, const int* __restrict__ ec,
+                                                          const double* __restrict__ ev, const int* __restrict__ ent_t,
+                                                          const double* __restrict__ Zs, int c_lo, int c_hi, int p_end,
+                                                          const int* __restrict__ sigma, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= p_end) return;
+  double s = 0.0;
+  for (long e = ptr[p] + lane; e < ptr[p + 1]; e += 64) {
+    const int cc = ec[e];
+    if (cc >= c_lo && cc < c_hi) s += ev[e] * Zs[ent_t[e]];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) out[sigma[p]] -= s;
+}
+
+static bool use_sparse_matvec(const LmiBlock& b) {
+  if (!b.sp_ok || opt_matvec_sparse == 1) return false;
+  if (opt_matvec_sparse == 2) return true;
+  return (double)b.ncq * 60.0 < (double)b.msz * (double)b.msz;      // ~4e-12 ncq msz s  vs  4 msz^3 / 6e13 s
+}
+
+// y += AA vec(W mat(AA'x) W) restricted to the pattern columns [q_lo, q_hi) of Z
+static int matvec_sparse_block(lrn_ctx* c, LmiBlock& b, const double* x, double* y, int q_lo, int q_hi, bool mirror) {
+  const int m = b.msz;
+  hipStream_t st = c->stream;
+  LRN_TRY(ensure(c, c->m1, (size_t)m * m * 8));
+  double* N = c->m1.as<double>();
+  hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, st, b.cq_ptr.as<long>(),
+                     b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, b.Zs.as<double>());
+  hipLaunchKernelGGL(sp_symmetrize_kernel, dim3((unsigned)((b.ncq + 255) / 256)), dim3(256), 0, st, b.Zs.as<double>(),
+                     b.pc_t.as<int>(), b.ncq, b.Mv.as<double>());
+  if (q_hi > q_lo) {
+    hipLaunchKernelGGL(sp_wm_kernel, dim3((m + 15) / 16, (q_hi - q_lo + 255) / 256), dim3(256), 0, st, b.pc_ptr.as<long>(),
+                       b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, q_lo, q_hi, N);
+    hipLaunchKernelGGL(sp_dot_kernel, dim3(q_hi - q_lo), dim3(256), 0, st, b.pc_ptr.as<long>(), b.pc_r.as<int>(),
+                       b.pc_t.as<int>(), b.W.as<double>(), N, m, q_lo, mirror ? 1 : 0, b.Zs.as<double>());
+    hipLaunchKernelGGL(sp_aa_times_kernel, dim3((b.npos_nz + 3) / 4), dim3(256), 0, st, b.ent_ptr.as<long>(),
+                       b.ent_c.as<int>(), b.ent_v.as<double>(), b.ent_t.as<int>(), b.Zs.as<double>(), q_lo, q_hi, b.npos_nz,
+                       b.sigma_d.as<int>(), y);
+  }
+  return LRN_OK;
+}
+
 int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
   const int m = b.msz;
   GemmDesc g1;     // P = W M   (M symmetric: read as M[n + k*m] -> direct-to-LDS path)
@@ -232,6 +365,10 @@ int matvec_dev(lrn_ctx* c, const double* x, double* y) {
   for (auto& b : c->lmi) {
     if (!b.have_W) return set_error(c, LRN_ERR_STATE, "W not set");
     const int m = b.msz;
+    if (use_sparse_matvec(b)) {
+      LRN_TRY(matvec_sparse_block(c, b, x, y, 0, m, true));
+      continue;
+    }
     LRN_TRY(ensure_m(c, m));
     double* M = c->m0.as<double>();
     LRN_TRY(aat_to_mat(c, b, x, M));
@@ -258,6 +395,10 @@ int matvec_partial_dev(lrn_ctx* c, const double* x, double* y, int rank, int wor
     const int r0 = std::min(m, rank * per), r1 = std::min(m, r0 + per);
     if (r1 <= r0) continue;
     const int nr = r1 - r0;
+    if (use_sparse_matvec(b)) {       // shard the pattern columns of Z instead of its rows
+      LRN_TRY(matvec_sparse_block(c, b, x, y, r0, r1, false));
+      continue;
+    }
     LRN_TRY(ensure_m(c, m));
     double* M = c->m0.as<double>();
     LRN_TRY(aat_to_mat(c, b, x, M));              // replicated: sparse, cheap

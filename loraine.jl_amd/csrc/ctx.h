@@ -29,6 +29,14 @@ struct LmiBlock {
   lrn::DBuf cq_q, cq_ptr;   // int64 [ncq], [ncq+1]
   lrn::DBuf cq_j;           // int32 constraint (natural index)
   lrn::DBuf cq_v;           // double AA value
+  // sparsity pattern of mat(AA'x) = the stored columns above, when no constraint is stored dense and
+  // the pattern is symmetric: sparse-aware mat-vec (cgops.hip, Z = W M W only where AA needs it)
+  bool sp_ok = false;
+  lrn::DBuf pc_ptr;         // int64 [msz+1] pattern column -> range of stored columns
+  lrn::DBuf pc_r;           // int32 [ncq] row of stored column t
+  lrn::DBuf pc_t;           // int32 [ncq] stored column holding the transposed entry
+  lrn::DBuf ent_t;          // int32 [nent] constraint entry -> stored column
+  lrn::DBuf Mv, Zs;         // double [ncq] values of M and of Z on the pattern
   // rank-one factors (datarank = -1): CSR by constraint (natural order)
   bool has_B = false;
   long bnnz = 0;

@@ -145,7 +145,7 @@ __global__ void build_constraint_kernel(const long* __restrict__ ptr, const int*
 using namespace lrn;
 
 static void free_block(LmiBlock& b) {
-  for (DBuf* d : {&b.ent_ptr, &b.ent_r, &b.ent_c, &b.ent_v, &b.Adense, &b.hidx, &b.sigma_d, &b.ipos_d, &b.cq_q, &b.cq_ptr, &b.cq_j, &b.cq_v, &b.b_ptr, &b.b_col,
+  for (DBuf* d : {&b.ent_ptr, &b.ent_r, &b.ent_c, &b.ent_v, &b.Adense, &b.hidx, &b.sigma_d, &b.ipos_d, &b.cq_q, &b.cq_ptr, &b.cq_j, &b.cq_v, &b.pc_ptr, &b.pc_r, &b.pc_t, &b.ent_t, &b.Mv, &b.Zs, &b.b_ptr, &b.b_col,
                   &b.b_val, &b.X, &b.S, &b.W, &b.G, &b.Gi, &b.Si, &b.D, &b.DDsi, &b.Vprev, &b.Cd, &b.Rd, &b.delX, &b.delS, &b.Xn, &b.Sn, &b.RNT,
                   &b.t0, &b.t1, &b.t2})
     release(*d);
@@ -297,6 +297,44 @@ extern "C" int lrn_upload_model(lrn_ctx* c, int nlmi, int nvar, const int64_t* m
       LRN_TRY(copy_in(c, b.cq_ptr.p, cq_ptr.data(), (size_t)(b.ncq + 1) * 8));
       LRN_TRY(copy_in(c, b.cq_j.p, cq_j.data(), cq_j.size() * 4));
       LRN_TRY(copy_in(c, b.cq_v.p, cq_v.data(), cq_v.size() * 8));
+      // pattern of mat(AA'x) for the sparse-aware mat-vec
+      b.sp_ok = false;
+      if (b.nd == 0 && b.ncq > 0 && b.ncq < 2000000000L && b.nent < 2000000000L) {
+        const long nq = b.ncq;
+        std::vector<long> pcp(m + 1, 0);
+        std::vector<int> pr(nq), pt(nq), et(b.nent);
+        for (long t = 0; t < nq; ++t) {
+          pr[t] = (int)(cq_q[t] % m);
+          pcp[cq_q[t] / m + 1]++;
+        }
+        for (long q = 0; q < m; ++q) pcp[q + 1] += pcp[q];
+        bool sym = true;
+        for (long t = 0; t < nq && sym; ++t) {
+          long key = cq_q[t] / m + (cq_q[t] % m) * m;       // (col, row) swapped
+          auto it = std::lower_bound(cq_q.begin(), cq_q.end(), key);
+          if (it == cq_q.end() || *it != key) sym = false;
+          else pt[t] = (int)(it - cq_q.begin());
+        }
+        for (long e = 0; e < b.nent && sym; ++e) {
+          long key = (long)er[e] + (long)ec[e] * m;
+          auto it = std::lower_bound(cq_q.begin(), cq_q.end(), key);
+          if (it == cq_q.end() || *it != key) sym = false;
+          else et[e] = (int)(it - cq_q.begin());
+        }
+        if (sym) {
+          LRN_TRY(ensure(c, b.pc_ptr, (size_t)(m + 1) * 8));
+          LRN_TRY(ensure(c, b.pc_r, (size_t)nq * 4));
+          LRN_TRY(ensure(c, b.pc_t, (size_t)nq * 4));
+          LRN_TRY(ensure(c, b.ent_t, (size_t)b.nent * 4));
+          LRN_TRY(ensure(c, b.Mv, (size_t)nq * 8));
+          LRN_TRY(ensure(c, b.Zs, (size_t)nq * 8));
+          LRN_TRY(copy_in(c, b.pc_ptr.p, pcp.data(), (size_t)(m + 1) * 8));
+          LRN_TRY(copy_in(c, b.pc_r.p, pr.data(), (size_t)nq * 4));
+          LRN_TRY(copy_in(c, b.pc_t.p, pt.data(), (size_t)nq * 4));
+          LRN_TRY(copy_in(c, b.ent_t.p, et.data(), (size_t)b.nent * 4));
+          b.sp_ok = true;
+        }
+      }
     }
     LRN_TRY(ensure(c, b.ent_ptr, (size_t)(nvar + 1) * 8));
     LRN_TRY(ensure(c, b.ent_r, (size_t)b.nent * 4));
@@ -399,6 +437,7 @@ extern "C" int lrn_synthetic_dense_model(lrn_ctx* c, int msz, int nvar, uint64_t
   b.ipos = b.sigma;
   b.nnz.assign(nvar, (long)msz * msz);
   b.qA = b.nd = b.q_wave = b.npos_nz = nvar;
+  b.sp_ok = false;
   b.nent = 0;
   std::vector<long> ptr(nvar + 1, 0);
   LRN_TRY(ensure(c, b.ent_ptr, (size_t)(nvar + 1) * 8));

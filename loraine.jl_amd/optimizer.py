@@ -135,7 +135,7 @@ class Optimizer:
     def dual_objective_value(self):
         s = self.solver
         m = s.model
-        val = sum(float(m.C[i].multiply(s.X[i]).sum()) for i in range(m.nlmi)) - m.b_const
+        val = sum(solvers._cdot(m.C[i], s.X[i]) for i in range(m.nlmi)) - m.b_const
         if m.nlin > 0:
             val += float(m.d_lin @ s.X_lin)
         return val if self.max_sense else -val

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 from . import solvers
-from .solvers import MySolver, _fro
+from .solvers import MySolver, _dense, _fro
 
 
 class ResidentSolver(MySolver):
@@ -24,7 +24,7 @@ class ResidentSolver(MySolver):
             self._normC = list(m.normC)
         else:
             for i in range(m.nlmi):
-                self.dev.ip_set_c(i, m.C[i].toarray())
+                self.dev.ip_set_c(i, _dense(m.C[i]))
             self._normC = [_fro(m.C[i]) for i in range(m.nlmi)]
 
     def initial_point(self):

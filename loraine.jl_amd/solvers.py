@@ -45,6 +45,15 @@ def _fro(M):
     return float(sp.linalg.norm(M)) if sp.issparse(M) else float(np.linalg.norm(M))
 
 
+def _dense(M):
+    """C[i] is sparse for file/array input and a dense array for the synthetic generators."""
+    return M.toarray() if sp.issparse(M) else np.asarray(M)
+
+
+def _cdot(Cm, X):
+    return float(Cm.multiply(X).sum()) if sp.issparse(Cm) else float(np.vdot(Cm, X))
+
+
 class Halpha:
     """src/Solvers.jl:149-162 -- the preconditioner data lives on the device; this object
     only remembers which one was set up in the predictor so the corrector reuses it."""
@@ -223,7 +232,7 @@ class MySolver:
         Rp = m.b.copy()
         for i in range(m.nlmi):
             Rp -= m.AA[i] @ _vec(self.X[i])
-            self.Rd[i] = m.C[i].toarray() - self.S[i] - _mat(m.AA[i].T @ self.y)
+            self.Rd[i] = _dense(m.C[i]) - self.S[i] - _mat(m.AA[i].T @ self.y)
         if m.nlin > 0:
             Rp -= m.C_lin @ self.X_lin
             self.Rd_lin = m.d_lin - self.S_lin - m.C_lin.T @ self.y
@@ -381,7 +390,7 @@ class MySolver:
         CX = 0.0
         for i in range(m.nlmi):
             nC = _fro(m.C[i])
-            cx = float(m.C[i].multiply(self.X[i]).sum())
+            cx = _cdot(m.C[i], self.X[i])
             CX += cx
             e2 += max(0.0, -_eigmin(self.X[i]) / (1.0 + nb))
             e3 += float(np.linalg.norm(self.Rd[i])) / (1.0 + nC)
@@ -444,6 +453,8 @@ class MySolver:
                             factor=d.timing("factor"), solve=d.timing("solve"),
                             prec_setup=d.timing("prec_setup"), pcg=d.timing("pcg"), svd=d.timing("prepw_svd")),
                 svd_sweeps=d.count("svd_sweeps"), find_step_ms=d.timing("find_step")))
+            if time.perf_counter() - t1 > getattr(self, "time_budget", float("inf")):
+                self.status = 4            # tools/c5_solve.py: wall-clock cap for exploratory runs
             if self.preconditioner == 4:
                 n_ = self.model.n
                 if ((self.cg_iter_cor / 2 > self.erank * self.model.nlmi * math.sqrt(n_) / 20

@@ -45,3 +45,72 @@ def synthetic_dense_solver(dev, msz, nvar, seed=20250614, options=None):
         raise ValueError("the synthetic model supports initpoint = 0 only (AA is not on the host)")
     solver = ResidentSolver(model, opts, device=dev)
     return solver, Halpha(solver.kit)
+
+
+# ------------------------------------------------------------------------------------------------
+# C5: builder-defined synthetic SDP with sparse constraints and a planted low-rank optimum
+# (SURVEY.md section 8d).  Host-side NumPy: the data is O(nvar) apart from the dense C.
+class LowRankProblem:
+    """max b'y  s.t.  S = C - sum_k y_k M_k >= 0   (dual: <M_k, X> = b_k, X >= 0), with
+
+      * M_k: symmetric, traceless, supported on a random 3 x 3 principal block (9 nnz, like the
+        3 x 3 blocks of thetaG11); AA[k, :] = vec(M_k), i.e. F_k = -M_k in SDPA terms;
+      * planted pair  X* = Q diag(lam) Q'  (rank r, trace msz),  S* = I - Q Q',  y* ~ 0.1 N(0,1),
+        b_k = <M_k, X*>,  C = S* + sum_k y*_k M_k.   X* S* = 0 and rank X* + rank S* = msz, so
+        (X*, y*, S*) is optimal and strictly complementary:  optimum  b'y* = <C, X*>.
+    """
+
+    def __init__(self, msz, nvar, rank=4, seed=20250615):
+        rng = np.random.default_rng(seed)
+        self.msz, self.nvar, self.rank, self.seed = int(msz), int(nvar), int(rank), int(seed)
+        i0 = rng.integers(0, msz, nvar)
+        d1 = rng.integers(1, msz, nvar)
+        d2 = rng.integers(1, msz - 1, nvar)
+        d2 = d2 + (d2 >= d1)
+        self.idx = np.stack([i0, (i0 + d1) % msz, (i0 + d2) % msz], axis=1)       # nvar x 3, distinct
+        R = rng.standard_normal((nvar, 3, 3))
+        blk = 0.5 * (R + R.transpose(0, 2, 1))
+        tr = np.trace(blk, axis1=1, axis2=2) / 3.0
+        blk[:, [0, 1, 2], [0, 1, 2]] -= tr[:, None]
+        self.blocks = blk                                                          # nvar x 3 x 3
+        Q, _ = np.linalg.qr(rng.standard_normal((msz, rank)))
+        lam = 1.0 + np.arange(rank) / rank
+        self.Q, self.lam = Q, lam * (msz / lam.sum())
+        Qk = Q[self.idx]                                                           # nvar x 3 x r
+        Xk = np.einsum("kia,a,kja->kij", Qk, self.lam, Qk)
+        self.b = np.einsum("kij,kij->k", blk, Xk)
+        self.ystar = 0.1 * rng.standard_normal(nvar)
+        self.optimum = float(self.b @ self.ystar)
+
+    def AA(self):
+        m, n = self.msz, self.nvar
+        r = np.repeat(self.idx, 3, axis=1).reshape(n, 3, 3)          # row index of entry (a, b): idx[a]
+        c = np.tile(self.idx, (1, 3)).reshape(n, 3, 3)               # col index: idx[b]
+        cols = (c.astype(np.int64) * m + r).reshape(n, 9)
+        order = np.argsort(cols, axis=1)
+        cols = np.take_along_axis(cols, order, axis=1)
+        vals = np.take_along_axis(self.blocks.reshape(n, 9), order, axis=1)
+        indptr = np.arange(0, 9 * n + 1, 9, dtype=np.int64)
+        return sp.csr_matrix((vals.ravel(), cols.ravel(), indptr), shape=(n, m * m))
+
+    def C_dense(self):
+        m = self.msz
+        Cd = np.eye(m) - self.Q @ self.Q.T
+        r = np.repeat(self.idx, 3, axis=1).ravel()
+        c = np.tile(self.idx, (1, 3)).ravel()
+        np.add.at(Cd, (r, c), (self.ystar[:, None, None] * self.blocks).ravel())
+        return np.asfortranarray(Cd)
+
+    def constraint(self, k):
+        """M_k as a sparse msz x msz matrix (tests / the CPU oracle)."""
+        ii = self.idx[k]
+        return sp.csc_matrix((self.blocks[k].ravel(), (np.repeat(ii, 3), np.tile(ii, 3))), shape=(self.msz, self.msz))
+
+    def model(self, kappa=8):
+        from .model import MyModel
+        n = self.nvar
+        nzA = np.full((n, 1), 9, dtype=np.int64)
+        sigmaA = np.arange(n, dtype=np.int64).reshape(n, 1)
+        qA = np.full((2, 1), n if 9 > kappa else 0, dtype=np.int64)
+        return MyModel(None, [self.AA()], [], [self.C_dense()], nzA, sigmaA, qA, self.b.copy(), 0.0, np.zeros(0),
+                       sp.csr_matrix((n, 0)), n, np.array([self.msz], dtype=np.int64), 0, 1)

@@ -238,3 +238,42 @@ def test_row_sharded_matvec_sums_to_full(dev):
     xs, ec, it = ShardedCG(dev, 0, 1).solve(h, 1e-8)
     xg, ec2, it2 = dev.pcg(h, 1e-8)
     assert ec == ec2 == 30 and abs(it - it2) <= 1 and relerr(xs, xg) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["thetaG11", "lowrank"])
+def test_sparse_pattern_matvec_matches_gemm_matvec(dev, case):
+    """MyA (Solvers.jl:582-614) two ways: W mat(AA'x) W by two dense GEMMs, or only on the sparsity
+    pattern the constraints read (option matvec_sparse); also column-sharded partial sums."""
+    from loraine_jl_amd._capi import ptr
+    rng = np.random.default_rng(11)
+    if case == "thetaG11":
+        model = lo.model_from_sdpa(os.path.join(GOLD, "thetaG11.dat-s"))
+    else:
+        from loraine_jl_amd.synthetic import LowRankProblem
+        model = LowRankProblem(300, 500, 3, seed=5).model()
+    m = int(model.msizes[0])
+    Gm = rng.standard_normal((m, m)) / np.sqrt(m) + np.diag(np.exp(rng.uniform(-2, 2, m)))
+    W = Gm @ Gm.T
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    dev.set_scaling(0, W, Gm)
+    x = rng.standard_normal(model.n)
+    try:
+        dev.set_option("matvec_sparse", 1)
+        dense = dev.matvec(x)
+        dev.set_option("matvec_sparse", 2)
+        sparse = dev.matvec(x)
+        acc = np.zeros(model.n)
+        for r in range(3):
+            dev.set_shard(r, 3)
+            part = np.zeros(model.n)
+            dev._chk(dev.lib.lrn_matvec_partial(dev.h, ptr(x), ptr(part)), "lrn_matvec_partial")
+            acc += part
+    finally:
+        dev.set_shard(0, 1)
+        dev.set_option("matvec_sparse", 0)
+    Mx = model.AA[0].T @ x
+    Mx = Mx.reshape(m, m, order="F"); Mx = 0.5 * (Mx + Mx.T)
+    ref = model.AA[0] @ (W @ Mx @ W).reshape(-1, order="F")
+    assert relerr(dense, ref) < 1e-12
+    assert relerr(sparse, ref) < 1e-12
+    assert relerr(acc, ref) < 1e-12
