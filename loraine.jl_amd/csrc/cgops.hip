@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void sp_aa_times_kernel(const long* __restrict
 static bool use_sparse_matvec(const LmiBlock& b) {
   if (!b.sp_ok || opt_matvec_sparse == 1) return false;
   if (opt_matvec_sparse == 2) return true;
-  return (double)b.ncq * 60.0 < (double)b.msz * (double)b.msz;      // ~4e-12 ncq msz s  vs  4 msz^3 / 6e13 s
+  // ~4e-12 ncq msz s against 4 msz^3 / 6e13 s; below msz ~ 1500 both are launch-bound and the GEMM path
+  // wins (thetaG11, msz = 801: 35 us per mat-vec)
+  return b.msz >= 1500 && (double)b.ncq * 60.0 < (double)b.msz * (double)b.msz;
 }
 
 // y += AA vec(W mat(AA'x) W) restricted to the pattern columns [q_lo, q_hi) of Z

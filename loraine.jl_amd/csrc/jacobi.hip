@@ -9,6 +9,8 @@
 //   * n <= 96: one workgroup keeps A and V in LDS and runs all sweeps in one launch.
 //   * larger n: one launch per round (n-1 rounds per sweep), columns streamed from L2/MALL.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "ctx.h"
 #include "jacobi.h"
@@ -152,6 +154,8 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(double* __restrict__ 
 //   jb_apply_kernel   P <- P R and V_panel <- V_panel R              (FP64 MFMA)
 // nbk-1 rounds make every pair of columns meet once per sweep.
 static constexpr int JB = 16;
+int opt_jacobi_inner = 0;     // sweeps over the pair's Gram matrix per round (more did not cut the outer sweeps: 1)
+int opt_jacobi_block = 0;     // column block width: 0 auto (32 for n >= 5000; measured crossover between 4000 and 6000), 16, 32
 
 __global__ __launch_bounds__(256) void jb_gram_kernel(const double* __restrict__ A, int n, int nbk2, int round,
                                                       int RC, double* __restrict__ Gpart) {
@@ -211,7 +215,7 @@ __device__ __forceinline__ bool jrot(double al, double be, double ga, double tol
 // (pair k1 x pair k2) -> one thread per block, every thread recomputes the two rotations it
 // needs from the diagonal blocks, G is double-buffered: ONE barrier per step.
 __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict__ Gpart, int nchunk, int n, int nbk2,
-                                                        int round, double tol, double* __restrict__ Rbuf,
+                                                        int round, double tol, int inner, double* __restrict__ Rbuf,
                                                         int* __restrict__ flags, int* __restrict__ nrot) {
   __shared__ double G[2][32][33];
   __shared__ double R[32][33];
@@ -249,7 +253,9 @@ __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict
   const int k1 = t >> 4, k2 = t & 15;
   int cur = 0;
   bool rotated = false;
-  for (int step = 0; step < 31; ++step) {
+  // inner > 1: further sweeps on the same Gram matrix (cheap next to streaming the panels at large n)
+  for (int istep = 0; istep < 31 * inner; ++istep) {
+    const int step = istep % 31;
     const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
     const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
     double c1, s1, c2, s2;
@@ -326,6 +332,213 @@ __global__ __launch_bounds__(256) void jb_apply_kernel(double* __restrict__ A, d
   }
 }
 
+
+// ------------------------------------------------------------------ 32-column blocks (large n)
+// Every round streams the whole matrix (Gram: read, apply: read + write), so at large n a sweep is
+// bound by HBM traffic = rounds x 3 x 8 n^2 bytes.  Doubling the block width halves the rounds;
+// the 64 x 64 Gram sweep (63 steps of 32 rotations, 1024 independent 2x2 blocks per step) costs more
+// per round but is amortised once n >= ~5000.  Same structure as the 16-column kernels above.
+static constexpr int JB2 = 32;
+__device__ __constant__ signed char jb2_tile_of[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+
+__global__ __launch_bounds__(256) void jb2_gram_kernel(const double* __restrict__ A, int n, int nbk2, int round, int RC,
+                                                       double* __restrict__ Gpart) {
+  __shared__ double part[10][256];
+  int I, J;
+  rr_pair(nbk2, round, blockIdx.x, &I, &J);
+  const int cI = I * JB2, cJ = J * JB2;
+  if (cI >= n) return;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int ci = lane & 15, kq = lane >> 4;
+  v4f64 acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = v4f64{0, 0, 0, 0};
+  const double* pc[4];
+  bool ok[4];
+#pragma unroll
+  for (int sb = 0; sb < 4; ++sb) {
+    int col = (sb < 2 ? cI : cJ) + 16 * (sb & 1) + ci;
+    ok[sb] = col < n;
+    pc[sb] = A + (long)(ok[sb] ? col : 0) * n;
+  }
+  const int rbeg = blockIdx.y * RC, rend = min(n, rbeg + RC);
+  // lane (ci, kq) holds rows r0 + 4 kq .. +3 of its column: 16 lanes cover 128 contiguous bytes.
+  // The next slab is loaded while the 40 MFMAs of the current one issue (few waves per SIMD).
+  const bool vec = (n & 1) == 0;            // 16-byte alignment of (col * n + row), row % 4 == 0
+  auto load = [&](int r0, double (&x)[4][4]) {
+    const int row = r0 + 4 * kq;
+    if (vec && row + 3 < rend) {
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        if (ok[sb]) {
+          const double2 lo = *reinterpret_cast<const double2*>(pc[sb] + row);
+          const double2 hi = *reinterpret_cast<const double2*>(pc[sb] + row + 2);
+          x[sb][0] = lo.x; x[sb][1] = lo.y; x[sb][2] = hi.x; x[sb][3] = hi.y;
+        } else {
+          x[sb][0] = x[sb][1] = x[sb][2] = x[sb][3] = 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[sb][j] = (ok[sb] && row + j < rend) ? pc[sb][row + j] : 0.0;
+    }
+  };
+  double xa[4][4], xb[4][4];
+  int r0 = rbeg + 16 * w;
+  if (r0 < rend) load(r0, xa);
+  for (; r0 < rend; r0 += 64) {
+    const bool more = r0 + 64 < rend;
+    if (more) load(r0 + 64, xb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int ti = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a; b < 4; ++b) {
+          acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a][j], xa[b][j], acc[ti], 0, 0, 0);
+          ++ti;
+        }
+    }
+    if (more) {
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[sb][j] = xb[sb][j];
+    }
+  }
+  // reduce the four waves in turn through one 20 KB image
+  for (int ph = 0; ph < 4; ++ph) {
+    if (w == ph) {
+#pragma unroll
+      for (int ti = 0; ti < 10; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int o = (kq + 4 * r) * 16 + ci;          // f64 C/D map: row = (lane>>4) + 4*reg, col = lane&15
+          part[ti][o] = (ph == 0 ? 0.0 : part[ti][o]) + acc[ti][r];
+        }
+    }
+    __syncthreads();
+  }
+  double* out = Gpart + ((long)blockIdx.x * gridDim.y + blockIdx.y) * 2560;
+  for (int e = t; e < 2560; e += 256) out[e] = part[e >> 8][e & 255];
+}
+
+// One (or `inner`) cyclic sweep(s) over the 64 x 64 Gram matrix: 63 steps of 32 disjoint rotations,
+// one thread per 2x2 block (pair k1 x pair k2), double-buffered, one barrier per step.
+__global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restrict__ Gpart, int nchunk, int n, int nbk2,
+                                                          int round, double tol, int inner, double* __restrict__ Rbuf,
+                                                          int* __restrict__ flags, int* __restrict__ nrot) {
+  extern __shared__ double jb2_sh[];
+  double (*G)[64][65] = reinterpret_cast<double (*)[64][65]>(jb2_sh);                 // [2][64][65]
+  double (*R)[65] = reinterpret_cast<double (*)[65]>(jb2_sh + 2 * 64 * 65);           // [64][65]
+  unsigned char (*sched)[32][2] = reinterpret_cast<unsigned char (*)[32][2]>(jb2_sh + 3 * 64 * 65);   // [63][32][2]
+  __shared__ int anyrot;
+  int I, J;
+  rr_pair(nbk2, round, blockIdx.x, &I, &J);
+  const int t = threadIdx.x;
+  if (I * JB2 >= n) {
+    if (t == 0) flags[blockIdx.x] = 0;
+    return;
+  }
+  if (t == 0) anyrot = 0;
+  for (int e = t; e < 63 * 32; e += 1024) {
+    int p, q;
+    rr_pair(64, e >> 5, e & 31, &p, &q);
+    sched[e >> 5][e & 31][0] = (unsigned char)p;
+    sched[e >> 5][e & 31][1] = (unsigned char)q;
+  }
+  const double* gp = Gpart + (long)blockIdx.x * nchunk * 2560;
+  for (int e = t; e < 4096; e += 1024) {
+    int i = e >> 6, j = e & 63;
+    int a = i >> 4, b = j >> 4;
+    int o = a <= b ? jb2_tile_of[a][b] * 256 + (i & 15) * 16 + (j & 15) : jb2_tile_of[b][a] * 256 + (j & 15) * 16 + (i & 15);
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += gp[(long)c * 2560 + o];
+    G[0][i][j] = s;
+    R[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int k1 = t >> 5, k2 = t & 31;
+  int cur = 0;
+  bool rotated = false;
+  for (int istep = 0; istep < 63 * inner; ++istep) {
+    const int step = istep % 63;
+    const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
+    const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
+    double c1, s1, c2, s2;
+    bool r1 = jrot(G[cur][p1][p1], G[cur][q1][q1], G[cur][p1][q1], tol, &c1, &s1);
+    bool r2 = jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
+    rotated |= r1 | r2;
+    double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
+    double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
+    double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
+    G[cur ^ 1][p1][p2] = c1 * t00 - s1 * t10;
+    G[cur ^ 1][p1][q2] = c1 * t01 - s1 * t11;
+    G[cur ^ 1][q1][p2] = s1 * t00 + c1 * t10;
+    G[cur ^ 1][q1][q2] = s1 * t01 + c1 * t11;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int i = k1 + 32 * h;
+      double x = R[i][p2], y = R[i][q2];
+      R[i][p2] = c2 * x - s2 * y;
+      R[i][q2] = s2 * x + c2 * y;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (rotated) anyrot = 1;
+  __syncthreads();
+  double* ro = Rbuf + (long)blockIdx.x * 4096;
+  for (int e = t; e < 4096; e += 1024) ro[e] = R[e >> 6][e & 63];
+  if (t == 0) {
+    flags[blockIdx.x] = anyrot;
+    if (anyrot) atomicAdd(nrot, 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void jb2_apply_kernel(double* __restrict__ A, double* __restrict__ V, int n, int nbk2,
+                                                        int round, int RC, const double* __restrict__ Rbuf,
+                                                        const int* __restrict__ flags) {
+  __shared__ double R[64][65];
+  if (!flags[blockIdx.x]) return;
+  double* Mx = blockIdx.z == 0 ? A : V;
+  int I, J;
+  rr_pair(nbk2, round, blockIdx.x, &I, &J);
+  const int cI = I * JB2, cJ = J * JB2;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int ci = lane & 15, kq = lane >> 4;
+  const double* ri = Rbuf + (long)blockIdx.x * 4096;
+  for (int e = t; e < 4096; e += 256) R[e >> 6][e & 63] = ri[e];
+  __syncthreads();
+  const int rbeg = blockIdx.y * RC, rend = min(n, rbeg + RC);
+  for (int r0 = rbeg + 16 * w; r0 < rend; r0 += 64) {
+    const int row = r0 + ci;
+    double pk[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      int k = 4 * ks + kq;
+      int col = k < 32 ? cI + k : cJ + k - 32;
+      pk[ks] = (row < rend && col < n) ? Mx[(long)row + (long)col * n] : 0.0;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      v4f64 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(R[4 * ks + kq][16 * h + ci], pk[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = 16 * h + kq + 4 * r;             // output column within the 64-column panel
+        int col = m < 32 ? cI + m : cJ + m - 32;
+        if (row < rend && col < n) Mx[(long)row + (long)col * n] = acc[r];
+      }
+    }
+  }
+}
+
 __global__ void set_identity_kernel(double* __restrict__ V, int n) {
   long total = (long)n * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
@@ -356,31 +569,48 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
     LRN_HIP(c, hipStreamSynchronize(st));
   } else {
     if (V && !v_init) hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, st, V, n);
-    const int nbk = (n + JB - 1) / JB;
+    const bool wide = opt_jacobi_block == 32 || (opt_jacobi_block == 0 && n >= 5000);
+    const int jb = wide ? JB2 : JB;
+    const int gsz = wide ? 2560 : 768, rsz = wide ? 4096 : 1024;
+    const int nbk = (n + jb - 1) / jb;
     const int nbk2 = (nbk + 1) & ~1;
     const int npair = nbk2 / 2;
-    int nchunk = (512 + npair - 1) / npair;
+    int nchunk = ((wide ? 1536 : 512) + npair - 1) / npair;
     nchunk = std::max(1, std::min(nchunk, (n + 63) / 64));
     int RC = (n + nchunk - 1) / nchunk;
     RC = ((RC + 63) / 64) * 64;
     nchunk = (n + RC - 1) / RC;
-    LRN_TRY(ensure(c, c->jscratch, ((size_t)npair * nchunk * 768 + (size_t)npair * 1024) * 8 + (size_t)npair * 4 + 64));
+    LRN_TRY(ensure(c, c->jscratch, ((size_t)npair * nchunk * gsz + (size_t)npair * rsz) * 8 + (size_t)npair * 4 + 64));
     double* Gpart = c->jscratch.as<double>();
-    double* Rbuf = Gpart + (size_t)npair * nchunk * 768;
-    int* flags = reinterpret_cast<int*>(Rbuf + (size_t)npair * 1024);
+    double* Rbuf = Gpart + (size_t)npair * nchunk * gsz;
+    int* flags = reinterpret_cast<int*>(Rbuf + (size_t)npair * rsz);
+    static const bool trace = getenv("LRN_JACOBI_TRACE") != nullptr;
+    const int inner = opt_jacobi_inner > 0 ? opt_jacobi_inner : 1;
+    const size_t sh2 = (size_t)3 * 64 * 65 * 8 + 63 * 32 * 2;
+    if (wide)
+      LRN_HIP(c, hipFuncSetAttribute((const void*)jb2_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
     for (; sweeps < max_sweeps;) {
       LRN_HIP(c, hipMemsetAsync(cnt, 0, 4, st));
       for (int round = 0; round < nbk2 - 1; ++round) {
-        hipLaunchKernelGGL(jb_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
-        hipLaunchKernelGGL(jb_rotate_kernel, dim3(npair), dim3(256), 0, st, Gpart, nchunk, n, nbk2, round, tol, Rbuf,
-                           flags, cnt);
-        hipLaunchKernelGGL(jb_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
-                           Rbuf, flags);
+        if (wide) {
+          hipLaunchKernelGGL(jb2_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
+          hipLaunchKernelGGL(jb2_rotate_kernel, dim3(npair), dim3(1024), sh2, st, Gpart, nchunk, n, nbk2, round, tol,
+                             inner, Rbuf, flags, cnt);
+          hipLaunchKernelGGL(jb2_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
+                             Rbuf, flags);
+        } else {
+          hipLaunchKernelGGL(jb_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
+          hipLaunchKernelGGL(jb_rotate_kernel, dim3(npair), dim3(256), 0, st, Gpart, nchunk, n, nbk2, round, tol,
+                             inner, Rbuf, flags, cnt);
+          hipLaunchKernelGGL(jb_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
+                             Rbuf, flags);
+        }
       }
       int h = 0;
       LRN_HIP(c, hipMemcpyAsync(&h, cnt, 4, hipMemcpyDeviceToHost, st));
       LRN_HIP(c, hipStreamSynchronize(st));
       ++sweeps;
+      if (trace) fprintf(stderr, "[jacobi n=%d jb=%d] sweep %d: %d of %d block pairs rotated\n", n, jb, sweeps, h, npair * (nbk2 - 1));
       if (h == 0) break;
     }
   }

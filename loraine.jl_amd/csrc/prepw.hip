@@ -35,14 +35,14 @@ __global__ void mirror_lower_kernel(double* __restrict__ A, int n) {
   }
 }
 
-// B[:,j] = A[:,j] * f(d[j]);  mode 0: d^-1/2, 1: d^1/2
+// B[:,j] = A[:,j] * f(d[j]);  mode 0: d^-1/2, 1: d^1/2, 2: d^-1
 __global__ void scale_cols_kernel(const double* __restrict__ A, const double* __restrict__ d, int n, int mode,
                                   double* __restrict__ B) {
   long total = (long)n * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     int j = (int)(e / n);
-    double s = sqrt(d[j]);
-    B[e] = mode == 0 ? A[e] / s : A[e] * s;
+    double s = mode == 2 ? d[j] : sqrt(d[j]);
+    B[e] = mode == 1 ? A[e] * s : A[e] / s;
   }
 }
 
@@ -127,30 +127,36 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   if (h != 0) { *info = 2; return LRN_OK; }
   hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, LX, n);
   hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, LS, n);
-  // CC = LS' LX ; SVD
+  // SVD of CC = LS' LX = U D V' by one-sided Jacobi on CC' = LX' LS: its columns are rotated by
+  // U and converge to V D, so V = (columns / D) needs no accumulation of rotations -- the rounds
+  // are bandwidth-bound (every round streams the whole matrix), this removes the V half of it.
   tic(c);
-  LRN_TRY(gemm_nn(st, n, LS, true, LX, false, CC));
-  // warm start: the right singular vectors of the previous IP iterate nearly orthogonalise
-  // the columns of the new CC, so Jacobi starts from CC*V_prev with V = V_prev
+  LRN_TRY(gemm_nn(st, n, LX, true, LS, false, CC));
+  // warm start: the left singular vectors of the previous IP iterate nearly orthogonalise the
+  // columns of the new CC'
   bool warm = b.have_Vprev && opt_jacobi_warm;
   if (warm) {
     LRN_TRY(gemm_nn(st, n, CC, false, b.Vprev.as<double>(), false, Y));
     LRN_HIP(c, hipMemcpyAsync(CC, Y, mm, hipMemcpyDeviceToDevice, st));
-    LRN_HIP(c, hipMemcpyAsync(V, b.Vprev.p, mm, hipMemcpyDeviceToDevice, st));
   }
   toc(c, "prepw_gemm");
   tic(c);
   int sweeps = 0;
-  LRN_TRY(jacobi_svd(c, CC, V, b.D.as<double>(), n, &sweeps, warm));
-  LRN_TRY(ensure(c, b.Vprev, mm));
-  LRN_HIP(c, hipMemcpyAsync(b.Vprev.p, V, mm, hipMemcpyDeviceToDevice, st));
-  b.have_Vprev = true;
+  LRN_TRY(jacobi_svd(c, CC, nullptr, b.D.as<double>(), n, &sweeps, false));
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, CC, b.D.as<double>(), n, 2, V);
   c->counts["svd_sweeps"] = sweeps;
   toc(c, "prepw_svd");
   tic(c);
   // G = LX (V D^-1/2)
   hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 0, CC);
   LRN_TRY(gemm_nn(st, n, LX, false, CC, false, b.G.as<double>()));
+  if (opt_jacobi_warm) {          // U = LS' G D^-1/2  (G = LS^-T U D^1/2) for the next warm start
+    LRN_TRY(ensure(c, b.Vprev, mm));
+    LRN_TRY(gemm_nn(st, n, LS, true, b.G.as<double>(), false, CC));
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, CC, b.D.as<double>(), n, 0,
+                       b.Vprev.as<double>());
+    b.have_Vprev = true;
+  }
   // Gi' = LX^-T (V D^1/2)
   hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 1, Y);
   LRN_TRY(trsm_left_lower(st, LX, n, n, LinvX, true, Y, n, n, tw));

@@ -412,10 +412,10 @@ class MySolver:
         self.dual_obj = -CX - dX
         if self.verb > 0 and self.status == 0:
             if self.kit == 0:
-                print("%3d %16.8e %9.2e %8.2f" % (self.iter, self.primal_obj, self.DIMACS_error, self.itertime))
+                print("%3d %16.8e %9.2e %8.2f" % (self.iter, self.primal_obj, self.DIMACS_error, self.itertime), flush=True)
             else:
                 print("%3d %16.8e %9.2e %9d %8.2f" % (self.iter, self.primal_obj, self.DIMACS_error,
-                                                      self.cg_iter_pre + self.cg_iter_cor, self.itertime))
+                                                      self.cg_iter_pre + self.cg_iter_cor, self.itertime), flush=True)
         if self.DIMACS_error < self.eDIMACS:
             self.status = 1
             self._say(f"Primal objective: {self.primal_obj}")

@@ -45,6 +45,23 @@ def test_jacobi_svd(dev, n):
     assert np.linalg.norm(U.T @ U - np.eye(n)) < 1e-9 * n
 
 
+@pytest.mark.parametrize("n", [130, 257, 500])
+def test_jacobi_svd_wide_blocks(dev, n):
+    """32-column block kernels (auto for n >= 3000) forced at small sizes, incl. ragged last blocks."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)) @ np.diag(np.logspace(0, -4, n)) @ rng.standard_normal((n, n))
+    dev.set_option("jacobi_block", 32)
+    try:
+        US, s, V, sweeps = dev.dbg_svd_jacobi(A)
+    finally:
+        dev.set_option("jacobi_block", 0)
+    assert 0 < sweeps < 40
+    assert relerr(A @ V, US) < 1e-12
+    assert np.linalg.norm(V.T @ V - np.eye(n)) < 1e-12 * n
+    sref = np.linalg.svd(A, compute_uv=False)
+    assert np.allclose(np.sort(s)[::-1], sref, rtol=1e-9, atol=1e-14 * sref[0])
+
+
 @pytest.mark.parametrize("m,cond", [(10, 1e2), (50, 1e4), (130, 1e6), (400, 1e8)])
 def test_prepare_w_matches_oracle_and_identities(dev, m, cond):
     X = _spd(m, 1, cond)

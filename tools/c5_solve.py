@@ -4,6 +4,7 @@ usage: c5_solve.py [msz nvar rank [maxit [budget_s]]]; the planted optimum b'y* 
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.stdout.reconfigure(line_buffering=True)
 import loraine_jl_amd
 from loraine_jl_amd import resident
 from loraine_jl_amd.synthetic import LowRankProblem
@@ -19,8 +20,12 @@ P = LowRankProblem(msz, nvar, rank)
 model = P.model()
 t_gen = time.perf_counter() - t0
 dev = loraine_jl_amd.Device(0)
+for kv in filter(None, os.environ.get("LRN_OPTS", "").split(",")):      # e.g. LRN_OPTS=jacobi_inner=3,matvec_sparse=1
+    k, v = kv.split("=")
+    dev.set_option(k, float(v))
 t0 = time.perf_counter()
-opts = dict(kit=1, preconditioner=prec, erank=rank, verb=1, maxit=maxit, eDIMACS=float(os.environ.get("C5_EDIMACS", "1e-5")))
+opts = dict(kit=1, preconditioner=prec, erank=rank, verb=1, maxit=maxit, eDIMACS=float(os.environ.get("C5_EDIMACS", "1e-5")),
+            tol_cg_min=float(os.environ.get("C5_TOL_CG_MIN", "1e-7")))
 solver, ha = resident.load(model, opts, device=dev)
 print("generate %.1f s, upload %.1f s" % (t_gen, time.perf_counter() - t0), flush=True)
 solver.time_budget = budget
@@ -39,5 +44,5 @@ rec = dict(msz=msz, nvar=nvar, rank=rank, preconditioner=prec, iters=len(tr), st
            svd_sweeps=[x["svd_sweeps"] for x in tr])
 print(json.dumps(rec), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(dict(rec, trace=[{k: v for k, v in x.items() if k != "errs"} for x in tr]),
+json.dump(dict(rec, trace=[dict(x, errs=[float(e) for e in x["errs"]]) for x in tr]),
           open(f"gpurun_out/c5_solve_{msz}_{nvar}_p{prec}.json", "w"), indent=1)
