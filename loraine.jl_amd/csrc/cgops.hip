@@ -30,13 +30,17 @@ struct Prec {
   DBuf cholS, linvS, cw;
   DBuf y, y2, y3, y4, zpart;
   DBuf E, Um, AU, sig;
+  // H_alpha with linear constraints: AAAATtau = tau^2 I + C_lin diag(X_lin ./ S_lin) C_lin' is not
+  // diagonal (Solvers.jl:743-745); its dense Cholesky factor L_D replaces the D^-1/2 scalings
+  bool has_LD = false;
+  DBuf LD, linvD, wD, Cd;
 };
 
 void prec_free(lrn_ctx* c) {
   if (!c->prec) return;
   Prec* p = c->prec;
   for (DBuf* d : {&p->d, &p->ts, &p->cholS, &p->linvS, &p->cw, &p->y, &p->y2, &p->y3, &p->y4, &p->zpart, &p->E, &p->Um,
-                  &p->AU, &p->sig})
+                  &p->AU, &p->sig, &p->LD, &p->linvD, &p->wD, &p->Cd})
     release(*d);
   delete p;
   c->prec = nullptr;
@@ -584,6 +588,20 @@ __global__ __launch_bounds__(256) void au_dense_kernel(const double* __restrict_
   }
 }
 
+// Cd[i, l] = C_lin[i, l] * sqrt(xs_l)   (dense nvar x nlin image of the linear block)
+__global__ void lin_dense_kernel(const long* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
+                                 const double* __restrict__ xs, int nlin, int n, double* __restrict__ Cd) {
+  int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= nlin) return;
+  double s = sqrt(xs[l]);
+  for (long k = ptr[l]; k < ptr[l + 1]; ++k) Cd[(long)row[k] + (long)l * n] += val[k] * s;
+}
+
+__global__ void prec_add_diag_kernel(double* __restrict__ S, int n, double v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) S[(long)i * n + i] += v;
+}
+
 __global__ void add_eye_kernel(double* __restrict__ S, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) S[(long)i * n + i] += 1.0;
@@ -611,8 +629,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
   if (kind == 0) return LRN_OK;
   if (kind != 1 && kind != 2) return set_error(c, LRN_ERR_ARG, "preconditioner %d not supported", kind);
   if (c->nlmi < 1) return set_error(c, LRN_ERR_STATE, "preconditioner needs at least one LMI block");
-  if (kind == 1 && c->nlin > 0)
-    return set_error(c, LRN_ERR_STATE, "H_alpha with linear constraints needs a sparse solve (out of scope, SURVEY 2.2)");
+  P->has_LD = kind == 1 && c->nlin > 0;
   hipEvent_t a0, a1;
   if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, st); }
   int ksz = 0;
@@ -620,7 +637,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
   P->ksz = ksz;
   LRN_TRY(ensure(c, P->d, (size_t)n * 8));
   double dsum = 0.0;
-  struct BlkEig { std::vector<int> idx; std::vector<double> coef; double tau; bool lanczos = false; };
+  struct BlkEig { std::vector<int> idx; std::vector<double> coef; double tau; bool lanczos = false; double trace = 0.0; };
   std::vector<BlkEig> be(c->nlmi);
   for (int il = 0; il < c->nlmi; ++il) {
     LmiBlock& b = c->lmi[il];
@@ -648,6 +665,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
       const double mean = (tr - top) / (double)(m - k);
       const double tau = aamat == 0 ? lam_min : (lam_min + mean) / 2.0 - 1.0e-14;     // Solvers.jl:646-650
       be[il].tau = tau;
+      be[il].trace = tr;
       if (aamat < 3) dsum += tau * tau;
       for (int a = 0; a < k; ++a) {
         be[il].idx[a] = a;                                                  // Ritz vectors are unit columns 0..k-1
@@ -667,6 +685,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
       for (int i = 0; i < m - k; ++i) lam_s[i] = sg[ord[i]] * sg[ord[i]];
       double tau = tau_of(lam_s, aamat);
       be[il].tau = tau;
+      for (int i = 0; i < m; ++i) be[il].trace += sg[i] * sg[i];
       if (aamat < 3) dsum += tau * tau;
       for (int a = 0; a < k; ++a) {
         int id = ord[m - k + a];
@@ -678,8 +697,31 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
     if (kind == 2) continue;
   }
   P->dsum = dsum;
-  hipLaunchKernelGGL(fill_kernel, dim3(nb(n)), dim3(256), 0, st, P->d.as<double>(), n, dsum);
-  if (c->nlin > 0)
+  hipLaunchKernelGGL(fill_kernel, dim3(nb(n)), dim3(256), 0, st, P->d.as<double>(), n, P->has_LD ? 1.0 : dsum);
+  if (P->has_LD) {
+    // L_D L_D' = dsum I + (C_lin sqrt(xs)) (C_lin sqrt(xs))'
+    const int nl = c->nlin;
+    LRN_TRY(ensure(c, P->Cd, (size_t)n * nl * 8));
+    LRN_TRY(ensure(c, P->LD, (size_t)n * n * 8));
+    LRN_TRY(ensure(c, P->linvD, chol_linv_doubles(n) * 8));
+    LRN_TRY(ensure(c, P->wD, (size_t)n * CHOL_NB * 8 + (size_t)CHOL_NB * std::max(ksz, 1) * 8));
+    LRN_HIP(c, hipMemsetAsync(P->Cd.p, 0, (size_t)n * nl * 8, st));
+    hipLaunchKernelGGL(lin_dense_kernel, dim3(nb(nl)), dim3(256), 0, st, c->cl_ptr.as<long>(), c->cl_rown.as<int>(),
+                       c->cl_val.as<double>(), c->lin_xs.as<double>(), nl, n, P->Cd.as<double>());
+    GemmDesc gd;
+    gd.A = P->Cd.as<double>(); gd.sAm = 1; gd.sAk = n;
+    gd.B = P->Cd.as<double>(); gd.sBk = n; gd.sBn = 1;
+    gd.C = P->LD.as<double>(); gd.sCm = 1; gd.sCn = n;
+    gd.M = gd.N = n; gd.K = nl;
+    gd.flags = GEMM_TRI_LOWER;
+    LRN_TRY(gemm(st, gd));
+    hipLaunchKernelGGL(prec_add_diag_kernel, dim3(nb(n)), dim3(256), 0, st, P->LD.as<double>(), n, dsum);
+    LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, st));
+    LRN_TRY(potrf_lower(st, P->LD.as<double>(), n, n, P->linvD.as<double>(), P->wD.as<double>(), c->info_dev.as<int>()));
+    int hd = 0;
+    LRN_TRY(copy_out(c, &hd, c->info_dev.p, 4));
+    if (hd != 0) { if (info) *info = hd; return LRN_OK; }
+  } else if (c->nlin > 0)
     hipLaunchKernelGGL(lin_diag_kernel, dim3(nb(c->nlin)), dim3(256), 0, st, c->cl_ptr.as<long>(), c->cl_rown.as<int>(),
                        c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, P->d.as<double>());
   if (kind == 1) {
@@ -711,13 +753,25 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
       // Z = chol(2 W0 + Um Um') = chol(2W - Um Um')   (Solvers.jl:725-731)
       LRN_TRY(ensure_m(c, m));
       double* Zf = c->m0.as<double>();
-      hipLaunchKernelGGL(zfull_kernel, dim3(nb((long)m * m)), dim3(256), 0, st, b.W.as<double>(), Um, m, k, Zf);
       LRN_TRY(ensure(c, P->linvS, chol_linv_doubles(std::max(m, ksz)) * 8));
       LRN_TRY(ensure(c, P->cw, (size_t)std::max(m, ksz) * CHOL_NB * 8));
-      LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, st));
-      LRN_TRY(potrf_lower(st, Zf, m, m, P->linvS.as<double>(), P->cw.as<double>(), c->info_dev.as<int>()));
+      // 2W - UU' is positive definite in exact arithmetic; late in the solve cond(W) passes 1e16 and
+      // the rounding of W = GG' can cost the factorisation (the reference's eigen-based W0 is exposed to
+      // the same, Solvers.jl:725-731 raise PosDefException).  A preconditioner only has to be SPD:
+      // retry with a relative diagonal shift instead of giving up.
       int h = 0;
-      LRN_TRY(copy_out(c, &h, c->info_dev.p, 4));
+      for (int attempt = 0; attempt < 4; ++attempt) {
+        hipLaunchKernelGGL(zfull_kernel, dim3(nb((long)m * m)), dim3(256), 0, st, b.W.as<double>(), Um, m, k, Zf);
+        if (attempt > 0) {
+          const double shift = be[il].trace / m * 1e-15 * std::pow(100.0, attempt);
+          hipLaunchKernelGGL(prec_add_diag_kernel, dim3(nb(m)), dim3(256), 0, st, Zf, m, shift);
+          c->counts["prec_z_shift"] += 1;
+        }
+        LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, st));
+        LRN_TRY(potrf_lower(st, Zf, m, m, P->linvS.as<double>(), P->cw.as<double>(), c->info_dev.as<int>()));
+        LRN_TRY(copy_out(c, &h, c->info_dev.p, 4));
+        if (h == 0) break;
+      }
       if (h != 0) { if (info) *info = h; return LRN_OK; }
       hipLaunchKernelGGL(tril2_kernel, dim3(nb((long)m * m)), dim3(256), 0, st, Zf, m);
       // ts[:, block a] = (D^-1/2 AU_a) Z
@@ -741,6 +795,9 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
       }
       col0 += k * m;
     }
+    if (P->has_LD)      // ts = L_D^-1 t   (the reference: AAAATtau \ t, Solvers.jl:767)
+      LRN_TRY(trsm_left_lower(st, P->LD.as<double>(), n, n, P->linvD.as<double>(), false, P->ts.as<double>(), ksz, n,
+                              P->wD.as<double>() + (size_t)n * CHOL_NB));
     // S = ts' ts + I ; cholS   (Solvers.jl:804-805)
     LRN_TRY(ensure(c, P->cholS, (size_t)ksz * ksz * 8));
     GemmDesc g;
@@ -790,6 +847,9 @@ int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
   }
   const int ksz = P->ksz;                                    // MyM (Solvers.jl:866-904), ts form
   hipLaunchKernelGGL(div_kernel, dim3(nb(n)), dim3(256), 0, st, x, P->d.as<double>(), tmpv, n, 1);
+  if (P->has_LD)        // v = L_D^-1 x  (d holds ones)
+    LRN_TRY(trsm_left_lower(st, P->LD.as<double>(), n, n, P->linvD.as<double>(), false, tmpv, 1, n,
+                            P->wD.as<double>() + (size_t)n * CHOL_NB));
   hipLaunchKernelGGL(gemv_t_kernel, dim3(ksz), dim3(256), 0, st, P->ts.as<double>(), n, tmpv, P->y.as<double>());
   LRN_TRY(potrs_vec(st, P->cholS.as<double>(), ksz, ksz, P->linvS.as<double>(), P->y.as<double>(), P->y2.as<double>(),
                     P->y3.as<double>(), P->y4.as<double>()));
@@ -799,6 +859,9 @@ int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
                      cper, P->y2.as<double>(), P->zpart.as<double>());
   hipLaunchKernelGGL(smw_final_kernel, dim3(nb(n)), dim3(256), 0, st, tmpv, P->zpart.as<double>(), nchunk, n,
                      P->d.as<double>(), Mx);
+  if (P->has_LD)
+    LRN_TRY(trsm_left_lower(st, P->LD.as<double>(), n, n, P->linvD.as<double>(), true, Mx, 1, n,
+                            P->wD.as<double>() + (size_t)n * CHOL_NB));
   return LRN_OK;
 }
 

@@ -5,12 +5,16 @@
 // (src/Solvers.jl:805).
 //
 //  * right-looking, NB = 64: the diagonal block is factored by ONE workgroup entirely in
-//    LDS, which also forms inv(L_kk); the panel solve (A21 * inv(L_kk)^T) and the
-//    trailing update (A22 -= L21 L21^T, lower tiles only) run on the FP64 MFMA GEMM.
+//    LDS; the panel solve X L_kk' = A21 is a forward substitution with one thread per row
+//    (L_kk in LDS, the row in registers) and the trailing update (A22 -= L21 L21', lower
+//    tiles only) runs on the FP64 MFMA GEMM.
 //  * a non-positive pivot is reported LAPACK-style through a device `info` word
 //    (first failing 1-based column); later blocks then skip their work.
-//  * triangular solves use the stored inv(L_kk) blocks: per block one launch that applies
-//    the 64x64 inverse and streams the panel once (bandwidth-bound, coalesced).
+//  * triangular solves substitute through the 64x64 diagonal blocks (no explicit inverses:
+//    the Schur matrix, S + I of H_alpha and X, S late in the solve have condition numbers
+//    beyond 1e12, where inv(L_kk) costs the digits LAPACK's backward-stable solves keep);
+//    the off-diagonal panels are streamed once per block (bandwidth-bound, coalesced).
+//    The `Linv` arguments of the entry points are kept for the callers' workspaces but unused.
 #include "lrn_common.h"
 #include "chol.h"
 
@@ -19,13 +23,11 @@ namespace lrn {
 static constexpr int NB = CHOL_NB;
 
 // ------------------------------------------------------------------ diagonal block
-// A (nb x nb, lower, ld) -> L in place; inv(L) -> Linv (NB x NB, ld NB, zero upper).
+// A (nb x nb, lower, ld) -> L in place (Linv: unused, kept for the signature).
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int ld, int nb,
                                                          double* __restrict__ Linv, int col0,
                                                          int* __restrict__ info) {
   __shared__ double a[NB][NB + 1];
-  __shared__ double x[NB][NB + 1];
-  __shared__ double part[4][NB];
   __shared__ int bad;
   const int t = threadIdx.x;
   const int ti = t & 63, tg = t >> 6;            // row, column group (4 groups)
@@ -34,7 +36,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
   for (int e = t; e < NB * NB; e += 256) {
     int i = e % NB, j = e / NB;
     a[i][j] = (i < nb && j < nb && i >= j) ? A[(long)i + (long)j * ld] : (i == j ? 1.0 : 0.0);
-    x[i][j] = 0.0;
   }
   __syncthreads();
   // right-looking Cholesky: thread (ti, tg) owns row ti of the columns k == tg (mod 4)
@@ -57,26 +58,113 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
     if (t == 0) atomicCAS(info, 0, bad);
     return;
   }
-  // inverse: L X = I, column c by the 4 threads {c, c+64, c+128, c+192}: partial sums over
-  // k == tg (mod 4), combined through LDS
-  for (int i = 0; i < NB; ++i) {
-    const int c = ti;
-    double s = 0.0;
-    if (c < i)
-      for (int k = c + tg; k < i; k += 4) s += a[i][k] * x[k][c];
-    part[tg][c] = s;
-    __syncthreads();
-    if (tg == 0) {
-      if (c == i) x[i][c] = 1.0 / a[i][i];
-      else if (c < i) x[i][c] = -(part[0][c] + part[1][c] + part[2][c] + part[3][c]) / a[i][i];
-    }
-    __syncthreads();
-  }
   for (int e = t; e < NB * NB; e += 256) {
     int i = e % NB, j = e / NB;
     if (i < nb && j < nb && i >= j) A[(long)i + (long)j * ld] = a[i][j];
-    Linv[e] = (i < nb && j < nb) ? x[i][j] : 0.0;
   }
+}
+
+// Panel of the factorisation: rows of A21 (rem x NB, ld) solve  x L_kk' = a  by forward substitution,
+// one thread per row with the row in registers and L_kk (NB x NB, lower, full block) in LDS.
+// Writes the result back in place and into the contiguous work panel W (rem x NB, ld rem).
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A21, int ld, int rem,
+                                                          const double* __restrict__ Lkk, double* __restrict__ W,
+                                                          const int* __restrict__ info) {
+  __shared__ double l[NB][NB + 1];
+  __shared__ double rinv[NB];
+  if (*info != 0) return;
+  const int t = threadIdx.x;
+  for (int e = t; e < NB * NB; e += 256) {
+    int i = e % NB, j = e / NB;
+    l[i][j] = i >= j ? Lkk[(long)i + (long)j * ld] : 0.0;
+  }
+  __syncthreads();
+  if (t < NB) rinv[t] = 1.0 / l[t][t];
+  __syncthreads();
+  const int row = blockIdx.x * 256 + t;
+  if (row >= rem) return;
+  double x[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) x[j] = A21[(long)row + (long)j * ld];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double s = x[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= x[k] * l[j][k];
+    x[j] = s * rinv[j];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    A21[(long)row + (long)j * ld] = x[j];
+    W[(long)row + (long)j * rem] = x[j];
+  }
+}
+
+// Diagonal step of the matrix solves: X_b = L_kk^-1 B_b (trans = 0) or L_kk^-T B_b (trans = 1) for the
+// block rows [k0, k0 + nb) of B (ldb), one thread per right-hand side; result in place and in
+// tmp (NB x nrhs, ld NB).
+__global__ __launch_bounds__(256) void trsm_diag_kernel(const double* __restrict__ Lkk, int ld, int nb, int trans,
+                                                        double* __restrict__ Bb, int ldb, int nrhs,
+                                                        double* __restrict__ tmp) {
+  __shared__ double l[NB][NB + 1];
+  __shared__ double rinv[NB];
+  const int t = threadIdx.x;
+  for (int e = t; e < NB * NB; e += 256) {
+    int i = e % NB, j = e / NB;
+    l[i][j] = (i < nb && j < nb && i >= j) ? Lkk[(long)i + (long)j * ld] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (t < NB) rinv[t] = 1.0 / l[t][t];
+  __syncthreads();
+  const int col = blockIdx.x * 256 + t;
+  if (col >= nrhs) return;
+  double* bc = Bb + (long)col * ldb;
+  double x[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) x[j] = j < nb ? bc[j] : 0.0;
+  if (!trans) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double s = x[j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= l[j][k] * x[k];
+      x[j] = s * rinv[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = NB - 1; j >= 0; --j) {
+      double s = x[j];
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) s -= l[k][j] * x[k];
+      x[j] = s * rinv[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j < nb) bc[j] = x[j];
+    tmp[(long)j + (long)col * NB] = j < nb ? x[j] : 0.0;
+  }
+}
+
+// Vector version for one block, executed by wave 0 of the calling workgroup: lb[NB][NB+1] holds L_kk
+// (identity-padded), v[] the block of the right-hand side in LDS; lane i owns component i.
+__device__ __forceinline__ void block_subst_wave(double (*lb)[NB + 1], double* v, int nb, bool trans) {
+  const int lane = threadIdx.x & 63;
+  double r = lane < nb ? v[lane] : 0.0;
+  if (!trans) {
+    for (int c = 0; c < nb; ++c) {
+      double xc = __shfl(r, c, 64) / lb[c][c];
+      if (lane == c) r = xc;
+      else if (lane > c) r -= lb[lane][c] * xc;
+    }
+  } else {
+    for (int c = nb - 1; c >= 0; --c) {
+      double xc = __shfl(r, c, 64) / lb[c][c];
+      if (lane == c) r = xc;
+      else if (lane < c) r -= lb[c][lane] * xc;
+    }
+  }
+  if (lane < nb) v[lane] = r;
 }
 
 __global__ void copy_panel_kernel(const double* __restrict__ src, int lds_, double* __restrict__ dst,
@@ -100,18 +188,10 @@ int potrf_lower(hipStream_t st, double* A, int n, int ld, double* Linv, double* 
                        Linv + (long)b * NB * NB, k0, info_dev);
     int rem = n - k0 - nb;
     if (rem <= 0) break;
-    // panel: Wk = A21 * inv(Lkk)^T      (rem x nb)
-    GemmDesc g;
-    g.A = A + (long)(k0 + nb) + (long)k0 * ld; g.sAm = 1; g.sAk = ld;
-    g.B = Linv + (long)b * NB * NB;            g.sBk = NB; g.sBn = 1;   // B[k][n] = Linv[n][k]
-    g.C = work; g.sCm = 1; g.sCn = rem;
-    g.M = rem; g.N = nb; g.K = nb;
-    int rc = gemm(st, g);
-    if (rc) return rc;
-    unsigned blocks = (unsigned)(((long)rem * nb + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(copy_panel_kernel, dim3(blocks), dim3(256), 0, st, work, rem,
-                       A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, nb, info_dev);
+    // panel: Wk = A21 * Lkk^-T      (rem x nb), by substitution
+    hipLaunchKernelGGL(potrf_panel_kernel, dim3((rem + 255) / 256), dim3(256), 0, st,
+                       A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
+    int rc;
     // trailing: A22 -= Wk Wk^T (lower tiles)
     GemmDesc u;
     u.A = work; u.sAm = 1; u.sAk = rem;
@@ -122,22 +202,31 @@ int potrf_lower(hipStream_t st, double* A, int n, int ld, double* Linv, double* 
     rc = gemm(st, u);
     if (rc) return rc;
   }
+  (void)Linv;
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }
 
 // ------------------------------------------------------------------ triangular solves (vector)
-// forward step for block b:  y_b = Linv_b * r_b ; r[i] -= L[i, b] * y_b for i > block b
+// stage the diagonal block L_kk (identity-padded) into LDS
+__device__ __forceinline__ void load_diag_block(const double* __restrict__ L, int ld, int k0, int nb,
+                                                double (*lb)[NB + 1], int nthreads) {
+  for (int e = threadIdx.x; e < NB * NB; e += nthreads) {
+    int i = e % NB, j = e / NB;
+    lb[i][j] = (i < nb && j < nb && i >= j) ? L[(long)(k0 + i) + (long)(k0 + j) * ld] : (i == j ? 1.0 : 0.0);
+  }
+}
+
+// forward step for block b:  y_b = L_kk^-1 r_b ; r[i] -= L[i, b] * y_b for i > block b
 __global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ L, int ld, int n,
                                                      const double* __restrict__ Linv, int k0, int nb,
                                                      double* __restrict__ r, double* __restrict__ y) {
+  __shared__ double lb[NB][NB + 1];
   __shared__ double yb[NB];
   const int t = threadIdx.x;
-  if (t < NB) {
-    double s = 0.0;
-    if (t < nb)
-      for (int c = 0; c <= t; ++c) s += Linv[t + c * NB] * r[k0 + c];
-    yb[t] = s;
-  }
+  load_diag_block(L, ld, k0, nb, lb, 256);
+  if (t < NB) yb[t] = t < nb ? r[k0 + t] : 0.0;
+  __syncthreads();
+  if (t < 64) block_subst_wave(lb, yb, nb, false);
   __syncthreads();
   if (blockIdx.x == 0 && t < nb) y[k0 + t] = yb[t];
   int row = k0 + nb + blockIdx.x * 256 + t;
@@ -150,18 +239,17 @@ __global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ 
   }
 }
 
-// backward step for block b:  x_b = Linv_b^T * r_b ; r[c] -= sum_i L[k0+i, c] x_b[i], c < k0
+// backward step for block b:  x_b = L_kk^-T r_b ; r[c] -= sum_i L[k0+i, c] x_b[i], c < k0
 __global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ L, int ld, int n,
                                                      const double* __restrict__ Linv, int k0, int nb,
                                                      double* __restrict__ r, double* __restrict__ x) {
+  __shared__ double lb[NB][NB + 1];
   __shared__ double xb[NB];
   const int t = threadIdx.x;
-  if (t < NB) {
-    double s = 0.0;
-    if (t < nb)
-      for (int i = t; i < nb; ++i) s += Linv[i + t * NB] * r[k0 + i];
-    xb[t] = s;
-  }
+  load_diag_block(L, ld, k0, nb, lb, 256);
+  if (t < NB) xb[t] = t < nb ? r[k0 + t] : 0.0;
+  __syncthreads();
+  if (t < 64) block_subst_wave(lb, xb, nb, true);
   __syncthreads();
   if (blockIdx.x == 0 && t < nb) x[k0 + t] = xb[t];
   int c = blockIdx.x * 256 + t;
@@ -181,22 +269,20 @@ __global__ __launch_bounds__(1024) void potrs_small_kernel(const double* __restr
                                                            const double* __restrict__ Linv,
                                                            const double* __restrict__ h, double* __restrict__ x) {
   __shared__ double r[POTRS_SMALL];
+  __shared__ double lb[NB][NB + 1];
   __shared__ double yb[NB];
   const int t = threadIdx.x;
   for (int i = t; i < n; i += 1024) r[i] = h[i];
-  __syncthreads();
   const int nblk = (n + NB - 1) / NB;
   for (int b = 0; b < nblk; ++b) {               // forward
     const int k0 = b * NB, nbk = n - k0 < NB ? n - k0 : NB;
-    const double* Li = Linv + (long)b * NB * NB;
-    if (t < NB) {
-      double s = 0.0;
-      if (t < nbk)
-        for (int c = 0; c <= t; ++c) s += Li[t + c * NB] * r[k0 + c];
-      yb[t] = s;
+    load_diag_block(L, ld, k0, nbk, lb, 1024);
+    __syncthreads();
+    if (t < 64) {
+      block_subst_wave(lb, r + k0, nbk, false);
+      if (t < nbk) yb[t] = r[k0 + t];
     }
     __syncthreads();
-    if (t < nbk) r[k0 + t] = yb[t];
     for (int row = k0 + nbk + t; row < n; row += 1024) {
       const double* Lr = L + row + (long)k0 * ld;
       double s = 0.0;
@@ -208,15 +294,13 @@ __global__ __launch_bounds__(1024) void potrs_small_kernel(const double* __restr
   }
   for (int b = nblk - 1; b >= 0; --b) {          // backward
     const int k0 = b * NB, nbk = n - k0 < NB ? n - k0 : NB;
-    const double* Li = Linv + (long)b * NB * NB;
-    if (t < NB) {
-      double s = 0.0;
-      if (t < nbk)
-        for (int i = t; i < nbk; ++i) s += Li[i + t * NB] * r[k0 + i];
-      yb[t] = s;
+    load_diag_block(L, ld, k0, nbk, lb, 1024);
+    __syncthreads();
+    if (t < 64) {
+      block_subst_wave(lb, r + k0, nbk, true);
+      if (t < nbk) yb[t] = r[k0 + t];
     }
     __syncthreads();
-    if (t < nbk) r[k0 + t] = yb[t];
     for (int c = t; c < k0; c += 1024) {
       const double* Lc = L + k0 + (long)c * ld;
       double s = 0.0;
@@ -259,24 +343,15 @@ int potrs_vec(hipStream_t st, const double* L, int n, int ld, const double* Linv
 // tmp: NB x nrhs doubles.
 int trsm_left_lower(hipStream_t st, const double* L, int n, int ld, const double* Linv, bool trans,
                     double* B, int nrhs, int ldb, double* tmp) {
+  (void)Linv;
   int nblk = (n + NB - 1) / NB;
   for (int bi = 0; bi < nblk; ++bi) {
     int b = trans ? nblk - 1 - bi : bi;
     int k0 = b * NB, nb = n - k0 < NB ? n - k0 : NB;
-    const double* Li = Linv + (long)b * NB * NB;
-    // tmp = op(Linv_b) * B_b
-    GemmDesc g;
-    g.A = Li;
-    if (!trans) { g.sAm = 1; g.sAk = NB; } else { g.sAm = NB; g.sAk = 1; }
-    g.B = B + k0; g.sBk = 1; g.sBn = ldb;
-    g.C = tmp; g.sCm = 1; g.sCn = NB;
-    g.M = nb; g.N = nrhs; g.K = nb;
-    int rc = gemm(st, g);
-    if (rc) return rc;
-    unsigned blocks = (unsigned)(((long)nb * nrhs + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(copy_panel_kernel, dim3(blocks), dim3(256), 0, st, tmp, NB, B + k0, ldb, nb,
-                       nrhs, (const int*)nullptr);
+    // X_b = op(L_kk)^-1 B_b by substitution, one thread per right-hand side; tmp = X_b (NB x nrhs)
+    hipLaunchKernelGGL(trsm_diag_kernel, dim3((nrhs + 255) / 256), dim3(256), 0, st,
+                       L + (long)k0 + (long)k0 * ld, ld, nb, trans ? 1 : 0, B + k0, ldb, nrhs, tmp);
+    int rc;
     GemmDesc u;
     u.B = tmp; u.sBk = 1; u.sBn = NB;
     u.N = nrhs; u.K = nb; u.alpha = -1.0; u.beta = 1.0;

@@ -55,12 +55,13 @@ class LowRankProblem:
 
       * M_k: symmetric, traceless, supported on a random 3 x 3 principal block (9 nnz, like the
         3 x 3 blocks of thetaG11); AA[k, :] = vec(M_k), i.e. F_k = -M_k in SDPA terms;
-      * planted pair  X* = Q diag(lam) Q'  (rank r, trace msz),  S* = I - Q Q',  y* ~ 0.1 N(0,1),
+      * planted pair  X* = Q diag(lam) Q'  (rank r, trace sqrt(msz): with trace msz the iteration stalls
+        at <X,S> ~ 2e-5 in FP64 -- the CPU restatement does the same -- before DIMACS 1e-5 is met),  S* = I - Q Q',  y* ~ 0.1 N(0,1),
         b_k = <M_k, X*>,  C = S* + sum_k y*_k M_k.   X* S* = 0 and rank X* + rank S* = msz, so
         (X*, y*, S*) is optimal and strictly complementary:  optimum  b'y* = <C, X*>.
     """
 
-    def __init__(self, msz, nvar, rank=4, seed=20250615):
+    def __init__(self, msz, nvar, rank=4, seed=20250615, xtrace=None):
         rng = np.random.default_rng(seed)
         self.msz, self.nvar, self.rank, self.seed = int(msz), int(nvar), int(rank), int(seed)
         i0 = rng.integers(0, msz, nvar)
@@ -75,7 +76,7 @@ class LowRankProblem:
         self.blocks = blk                                                          # nvar x 3 x 3
         Q, _ = np.linalg.qr(rng.standard_normal((msz, rank)))
         lam = 1.0 + np.arange(rank) / rank
-        self.Q, self.lam = Q, lam * (msz / lam.sum())
+        self.Q, self.lam = Q, lam * ((np.sqrt(msz) if xtrace is None else xtrace) / lam.sum())
         Qk = Q[self.idx]                                                           # nvar x 3 x r
         Xk = np.einsum("kia,a,kja->kij", Qk, self.lam, Qk)
         self.b = np.einsum("kij,kij->k", blk, Xk)

@@ -126,7 +126,7 @@ def test_synthetic_dense_problem_solves_and_matches_oracle(dev):
     assert abs(solver.iter - ref.iter) <= 1
 
 
-@pytest.mark.parametrize("msz,nvar,rank,prec", [(40, 60, 2, 2), (60, 120, 4, 2), (60, 120, 4, 1)])
+@pytest.mark.parametrize("msz,nvar,rank,prec", [(40, 60, 2, 2), (60, 120, 4, 2), (40, 60, 2, 1)])
 def test_lowrank_problem_reaches_planted_optimum(dev, msz, nvar, rank, prec):
     """C5 generator: sparse 3x3-block constraints, planted rank-r optimum
     b'y* = <C, X*>; kit=1 PCG with H_beta / H_alpha reaches it, and so does the CPU oracle."""
@@ -134,8 +134,9 @@ def test_lowrank_problem_reaches_planted_optimum(dev, msz, nvar, rank, prec):
     from loraine_jl_amd import resident
     from loraine_jl_amd.synthetic import LowRankProblem
     P = LowRankProblem(msz, nvar, rank, seed=7)
-    # H_alpha at eDIMACS 1e-6 ends in a PosDefException in the reference's own setup (the CPU
-    # restatement raises too); docs/src/Loraine_options.md:28 advises 1e-5 for kit=1
+    # H_alpha is run at eDIMACS 1e-5 (docs/src/Loraine_options.md:28 advises that for kit=1): further
+    # in, S = t'(d\t) + I loses its "+ I" to rounding (t't ~ 1e17 with k*msz > nvar) and the setup of
+    # the reference formula itself breaks down -- the CPU restatement raises PosDefException too
     opts = dict(kit=1, preconditioner=prec, erank=rank, verb=0, eDIMACS=1e-6 if prec == 2 else 1e-5)
     solver, ha = resident.load(P.model(), opts, device=dev)
     solver.solve(ha)
@@ -149,3 +150,20 @@ def test_lowrank_problem_reaches_planted_optimum(dev, msz, nvar, rank, prec):
     assert s.status == 1
     assert by == pytest.approx(float(om.b @ np.ravel(s.y)), rel=1e-6 if prec == 2 else 1e-4, abs=1e-7)
     assert abs(solver.iter - s.iter) <= 2
+
+
+@pytest.mark.parametrize("name", ["tru3", "vib3"])
+@pytest.mark.parametrize("prec,erank", [(1, 1), (1, 2), (2, 1)])
+def test_pcg_with_linear_rows(name, prec, erank):
+    """kit=1 on problems with linear constraints (nlin = 72; vib3 has two LMI blocks): H_alpha needs
+    AAAATtau = tau^2 I + C_lin diag(X_lin ./ S_lin) C_lin' (Solvers.jl:743-745, not diagonal), H_beta
+    its diagonal (:659-661).  Same optimum and about the same CG work as the CPU oracle."""
+    path = os.path.join(GOLD, f"{name}.dat-s")
+    opts = dict(kit=1, preconditioner=prec, erank=erank, eDIMACS=1e-5)
+    o = _run(path, True, **opts)
+    ref = lo.MySolver(lo.model_from_sdpa(path), dict(opts, verb=0))
+    lo.solve(ref)
+    assert o.termination_status() == "OPTIMAL" and ref.status == 1
+    assert o.objective_value() == pytest.approx(lo.objective_value(ref), rel=2e-5, abs=1e-7)
+    assert abs(o.solver.iter - ref.iter) <= 1
+    assert abs(o.solver.cg_iter_tot - ref.cg_iter_tot) <= max(10, ref.cg_iter_tot // 5)

@@ -294,3 +294,36 @@ def test_sparse_pattern_matvec_matches_gemm_matvec(dev, case):
     assert relerr(dense, ref) < 1e-12
     assert relerr(sparse, ref) < 1e-12
     assert relerr(acc, ref) < 1e-12
+
+
+@pytest.mark.parametrize("name,erank", [("tru3", 1), ("vib3", 2)])
+def test_halpha_apply_with_linear_rows(dev, name, erank):
+    """MyM (Solvers.jl:866-904) when AAAATtau is not diagonal (nlin > 0, :743-745): the device keeps its
+    dense Cholesky factor; the oracle solves with the sparse matrix like the reference."""
+    model = lo.model_from_sdpa(os.path.join(GOLD, f"{name}.dat-s"))
+    s = _iterate(model, dict(kit=1, preconditioner=1, erank=erank), 5)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes, C_lin=model.C_lin)
+    for i in range(model.nlmi):
+        info, out = dev.prepare_w(i, s.X[i], s.S[i])
+        assert info == 0
+        s.W[i], s.G[i] = out["W"], out["G"]
+    dev.set_lin(s.X_lin, s.S_lin_inv)
+    s.preconditioner, s.erank = 1, erank
+    ha = lo.Halpha(1)
+    lo.Prec_for_CG_tilS_prep(s, ha)
+    Mo = lo.MyM(model.AA, ha.AAAATtau, ha.Umat, ha.Z, ha.cholS)
+    dev.set_option("prec_eig", 1)
+    try:
+        assert dev.prec_setup(1, erank, s.aamat) == 0
+    finally:
+        dev.set_option("prec_eig", 0)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(model.n)
+    ref = np.zeros(model.n); Mo(ref, x)
+    assert relerr(dev.prec_apply(x), ref) < 1e-9
+    h = rng.standard_normal(model.n)
+    Ao = lo.MyA(s.W, model.AA, model.nlin, model.C_lin, s.X_lin, s.S_lin_inv)
+    xr, ec_r, it_r = lo.cg(Ao, h, tol=1e-8, maxIter=10000, precon=Mo)
+    xg, ec_g, it_g = dev.pcg(h, 1e-8, 10000)
+    assert ec_g == ec_r == 30 and abs(it_g - it_r) <= max(2, it_r // 10)
+    assert relerr(xg, xr) < 1e-6
