@@ -16,6 +16,7 @@ extern int opt_prec_eig;
 extern int opt_matvec_sparse;
 extern int opt_jacobi_inner;
 extern int opt_jacobi_block;
+extern int opt_jacobi_wgs;
 }
 
 extern "C" {
@@ -78,6 +79,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
+  else if (!strcmp(key, "jacobi_wgs")) lrn::opt_jacobi_wgs = (int)value;
   else if (!strcmp(key, "jacobi_block")) lrn::opt_jacobi_block = (int)value;
   else if (!strcmp(key, "jacobi_inner")) lrn::opt_jacobi_inner = (int)value;
   else if (!strcmp(key, "matvec_sparse")) lrn::opt_matvec_sparse = (int)value;

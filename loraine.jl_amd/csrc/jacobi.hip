@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(double* __restrict__ 
 // nbk-1 rounds make every pair of columns meet once per sweep.
 static constexpr int JB = 16;
 int opt_jacobi_inner = 0;     // sweeps over the pair's Gram matrix per round (more did not cut the outer sweeps: 1)
+int opt_jacobi_wgs = 0;       // workgroups per Gram / apply launch the row chunking aims for: 0 auto
 int opt_jacobi_block = 0;     // column block width: 0 auto (32 for n >= 5000; measured crossover between 4000 and 6000), 16, 32
 
 __global__ __launch_bounds__(256) void jb_gram_kernel(const double* __restrict__ A, int n, int nbk2, int round,
@@ -196,15 +197,33 @@ __global__ __launch_bounds__(256) void jb_gram_kernel(const double* __restrict__
 
 // Plane-rotation parameters that annihilate the (p,q) Gram entry (Hestenes / same formula as the
 // scalar kernel); returns false when the pair is already orthogonal to tolerance.
+// The rotation parameters sit on the critical path of every step of the Gram sweep (31 or 63 dependent
+// steps per round): v_rsq_f64 / v_rcp_f64 seeds with two Newton steps (full double accuracy for the
+// normal-range arguments that occur here) instead of the IEEE sqrt / divide expansions.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double hx = 0.5 * x;
+  y = y * (1.5 - hx * y * y);
+  y = y * (1.5 - hx * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+
 __device__ __forceinline__ bool jrot(double al, double be, double ga, double tol, double* c, double* s) {
   *c = 1.0; *s = 0.0;
   if (!(ga * ga > tol * tol * al * be)) return false;      // |ga| > tol sqrt(al be), also rejects NaN
-  // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), written with one
-  // division:  t = 2 ga / (d + sign(d) sqrt(d^2 + 4 ga^2)),  d = be - al
+  // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), written as
+  //   t = 2 ga / (d + sign(d) sqrt(d^2 + 4 ga^2)),  d = be - al
   double d = be - al, g2 = 2.0 * ga;
-  double h = sqrt(d * d + g2 * g2);
-  double tt = g2 / (d >= 0.0 ? d + h : d - h);
-  double cc = 1.0 / sqrt(1.0 + tt * tt);
+  double r2 = d * d + g2 * g2;
+  double h = r2 * fast_rsqrt(r2);
+  double tt = g2 * fast_rcp(d >= 0.0 ? d + h : d - h);
+  double cc = fast_rsqrt(1.0 + tt * tt);
   *c = cc;
   *s = cc * tt;
   return true;
@@ -258,10 +277,15 @@ __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict
     const int step = istep % 31;
     const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
     const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
+    // one rotation per thread (pair k2); the row pair's (k1) comes from the lane of this wave whose
+    // k2 equals my k1 -- halves the dependent FP64 chain of a step
     double c1, s1, c2, s2;
-    bool r1 = jrot(G[cur][p1][p1], G[cur][q1][q1], G[cur][p1][q1], tol, &c1, &s1);
-    bool r2 = jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
-    rotated |= r1 | r2;
+    rotated |= jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
+    {
+      const int src = (threadIdx.x & 0x30) | k1;
+      c1 = __shfl(c2, src, 64);
+      s1 = __shfl(s2, src, 64);
+    }
     // 2x2 block (pair k1 rows, pair k2 columns):  B' = J1' B J2
     double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
     double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
@@ -469,9 +493,12 @@ __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restri
     const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
     const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
     double c1, s1, c2, s2;
-    bool r1 = jrot(G[cur][p1][p1], G[cur][q1][q1], G[cur][p1][q1], tol, &c1, &s1);
-    bool r2 = jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
-    rotated |= r1 | r2;
+    rotated |= jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
+    {
+      const int src = (threadIdx.x & 0x20) | k1;      // lane of this wave with k2 == my k1
+      c1 = __shfl(c2, src, 64);
+      s1 = __shfl(s2, src, 64);
+    }
     double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
     double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
     double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
@@ -575,7 +602,8 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
     const int nbk = (n + jb - 1) / jb;
     const int nbk2 = (nbk + 1) & ~1;
     const int npair = nbk2 / 2;
-    int nchunk = ((wide ? 1536 : 512) + npair - 1) / npair;
+    const int wg_target = opt_jacobi_wgs > 0 ? opt_jacobi_wgs : (wide ? 1536 : (n < 1500 ? 256 : 512));
+    int nchunk = (wg_target + npair - 1) / npair;
     nchunk = std::max(1, std::min(nchunk, (n + 63) / 64));
     int RC = (n + nchunk - 1) / nchunk;
     RC = ((RC + 63) / 64) * 64;

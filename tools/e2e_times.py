@@ -13,6 +13,9 @@ cases = [("theta1", dict(kit=0, eDIMACS=1e-6, initpoint=1, aamat=2), 0),
          ("thetaG11", dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5), 0)]
 only = [a for a in sys.argv[1:] if not a.startswith("--")]
 out = {}
+_dev = loraine_jl_amd.Device(0)
+for kv in filter(None, os.environ.get("LRN_OPTS", "").split(",")):
+    k, v = kv.split("="); _dev.set_option(k, float(v))
 for name, opts, dr in cases:
     if only and name not in only:
         continue
