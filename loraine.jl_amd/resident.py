@@ -84,6 +84,8 @@ class ResidentSolver(MySolver):
         if self.kit == 0:
             mode = -1 if (self.datarank == -1 and m.nlmi > 0) else 0
             dev.schur_assemble(mode)                                         # [GPU]
+            if self.dist is not None:
+                self.dist.allgather(dev)                                     # multi-GPU: column blocks -> all ranks
         h = self.Rp.copy()
         if m.nlmi > 0:
             h += dev.ip_rhs_pred()                                           # [GPU] makeRHS

@@ -83,9 +83,16 @@ class SchurExchange:
     def allgather(self):
         import torch
         import torch.distributed as dist
+        self.dev.set_shard(self.rank, self.world)
         self.dev.schur_export_shard(self.shard)
-        dist.all_gather_into_tensor(self.gathered, self.shard, group=self.group)    # RCCL over xGMI
-        torch.cuda.current_stream().synchronize()
+        if dist.get_backend(self.group) == "gloo":        # rehearsal on a one-GPU box: stage through the host
+            g_host = torch.empty(self.gathered.shape, dtype=torch.float64)
+            dist.all_gather_into_tensor(g_host, self.shard.cpu(), group=self.group)
+            self.gathered.copy_(g_host)
+            torch.cuda.synchronize()
+        else:
+            dist.all_gather_into_tensor(self.gathered, self.shard, group=self.group)    # RCCL over xGMI
+            torch.cuda.current_stream().synchronize()
         self.dev.schur_import_all(self.gathered)
 
 
@@ -138,20 +145,64 @@ class ShardedCG:
         dev = self.dev
         b = torch.as_tensor(np.asarray(h, float)).cuda()
 
+        # the library works on its own HIP stream: torch's stream must have finished writing a tensor
+        # before its pointer is handed over (the library's calls are blocking, so the way back is safe)
         def mv(p):
             out = torch.empty_like(p)
+            torch.cuda.current_stream().synchronize()
             dev._chk(dev.lib.lrn_matvec_partial(dev.h, ptr(p), ptr(out)), "lrn_matvec_partial")
             return out
 
+        gloo = self.world > 1 and dist.get_backend(self.group) == "gloo"
+
         def ar(v):
-            if self.world > 1:
-                dist.all_reduce(v, group=self.group)
+            if gloo:                                       # rehearsal: host-staged
+                h_ = v.cpu()
+                dist.all_reduce(h_, group=self.group)
+                v.copy_(h_)
+            elif self.world > 1:
+                dist.all_reduce(v, group=self.group)       # RCCL
             return v
 
         def pc(r):
             out = torch.empty_like(r)
+            torch.cuda.current_stream().synchronize()
             dev._chk(dev.lib.lrn_prec_apply(dev.h, ptr(r), ptr(out)), "lrn_prec_apply")
             return out
 
         x, ec, it = pcg_allreduce(mv, ar, pc, b, tol, max_iter, xp=torch)
         return x.cpu().numpy(), ec, it
+
+
+class DistributedHotPath:
+    """Attach to a solver (`solvers.MySolver` / `resident.ResidentSolver`) to run the interior-point
+    loop with one process per GPU: every rank drives the same (replicated, deterministic) iteration and
+    only the hot path is sharded -- kit=0: owned Schur column blocks + one all-gather before the
+    replicated Cholesky; kit=1: partial mat-vec + one all-reduce of an nvar-vector per CG iteration
+    (SURVEY.md 8e).  prepare_W, find_step and the preconditioner setup are replicas."""
+
+    def __init__(self, solver, rank, world, group=None):
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self._exchange = None
+        self._cg = None
+        solver.dist = self
+        # the C library shards Schur columns in sigma-position space, which exists for one LMI block;
+        # multi-block problems assemble replicated (every rank the whole matrix, no exchange)
+        self.shard_schur = self.world > 1 and (solver.kit == 1 or solver.model.nlmi == 1)
+        if self.shard_schur:
+            solver.dev.set_shard(self.rank, self.world)     # assembly from now on covers the owned column blocks
+        else:
+            solver.dev.set_shard(0, 1)
+
+    def allgather(self, dev):
+        if not self.shard_schur:
+            return
+        if self._exchange is None:
+            self._exchange = SchurExchange(dev, self.rank, self.world, self.group)
+        self._exchange.allgather()
+
+    def pcg(self, dev, h, tol, max_iter=10000):
+        if self._cg is None:
+            self._cg = ShardedCG(dev, self.rank, self.world, self.group)
+        dev.set_shard(self.rank, self.world)
+        return self._cg.solve(h, tol, max_iter)

@@ -81,6 +81,7 @@ class MySolver:
         self.model = model
         self._check_ranges()
         self.cg_iter_tot = 0
+        self.dist = None                 # sharding.DistributedHotPath when run with one process per GPU
         self.status = 0
         self.trace = []
         self.dev = device if device is not None else Device(device_index)
@@ -221,7 +222,10 @@ class MySolver:
             if info != 0:
                 raise np.linalg.LinAlgError("PosDefException in preconditioner setup")
             halpha.ready = True
-        x, _exit_code, iters = self.dev.pcg(h, self.tol_cg, 10000)            # exit code ignored (:134)
+        if self.dist is not None:                                              # multi-GPU: all-reduce PCG
+            x, _exit_code, iters = self.dist.pcg(self.dev, h, self.tol_cg, 10000)
+        else:
+            x, _exit_code, iters = self.dev.pcg(h, self.tol_cg, 10000)        # exit code ignored (:134)
         return x, iters
 
     # ------------------------------------------------------------------ predictor / corrector
@@ -242,6 +246,8 @@ class MySolver:
         if self.kit == 0:
             mode = -1 if (self.datarank == -1 and m.nlmi > 0) else 0
             dev.schur_assemble(mode)                                           # [GPU] makeBBBB*
+            if self.dist is not None:
+                self.dist.allgather(dev)                                       # multi-GPU: column blocks -> all ranks
         if m.nlmi > 0:
             h = dev.make_rhs(self.Rp, [self.Rd[i] + self.S[i] for i in range(m.nlmi)])   # [GPU] makeRHS
         else:

@@ -7,3 +7,6 @@ export LRN_BENCH_BACKEND=gloo LRN_BENCH_ONE_GPU=1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
    bench.py --gpus 2 --steps 2 --warmup 1 --msz 512 --nvar 700 --no-cpu-baseline
 python tools/check_sharded_solve.py
+# full interior-point solves with the hot path sharded over the 2 ranks (kit=0 all-gather, kit=1 all-reduce)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+   tools/solve_multirank.py
