@@ -147,7 +147,9 @@ int lrn_ip_update(lrn_ctx* ctx, int predict, const double* alpha, const double* 
 /* per block 5 numbers: <X,S>, eigmin(X), eigmin(S), ||Rd||_F, <C,X>
  * (find_mu src/Solvers.jl:480-494, check_convergence :496-511) */
 int lrn_ip_stats(lrn_ctx* ctx, double* out5);
-/* smallest eigenvalue of a symmetric n x n matrix (unit test of the Lanczos kernel) */
+/* smallest eigenvalue of a symmetric n x n matrix: steps != NULL -> the plain Lanczos Ritz value (unit
+ * test of the kernel); steps == NULL -> the Cholesky-certified value lrn_ip_find_step / lrn_ip_stats use
+ * (eigmin of src/predictor_corrector.jl:272,285 and src/Solvers.jl:503,505) */
 int lrn_dbg_eigmin(lrn_ctx* ctx, int n, const double* M, double* lam, int* steps);
 /* k largest eigenpairs (ascending; U_top n x k column-major, may be NULL), smallest eigenvalue and
  * trace of a symmetric matrix: what the preconditioner setup consumes of `eigen(W)`

@@ -17,6 +17,7 @@ extern int opt_matvec_sparse;
 extern int opt_jacobi_inner;
 extern int opt_jacobi_block;
 extern int opt_jacobi_wgs;
+extern double opt_pivot_boost;
 }
 
 extern "C" {
@@ -63,6 +64,7 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->redout);
   release(c->lzbuf);
   release(c->lxbuf);
+  release(c->ezbuf);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -79,6 +81,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
+  else if (!strcmp(key, "pivot_boost")) lrn::opt_pivot_boost = value;
   else if (!strcmp(key, "jacobi_wgs")) lrn::opt_jacobi_wgs = (int)value;
   else if (!strcmp(key, "jacobi_block")) lrn::opt_jacobi_block = (int)value;
   else if (!strcmp(key, "jacobi_inner")) lrn::opt_jacobi_inner = (int)value;

@@ -160,23 +160,48 @@ __global__ __launch_bounds__(256) void aa_dense_dot_rows_kernel(const double* __
   if (threadIdx.x == 0) out[sigma[blockIdx.x]] -= sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// linear block: t_l = xs_l * sum_i C[i,l] x_i ; y_i += C[i,l] t_l
-__global__ void lin_matvec_kernel(const long* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
-                                  const double* __restrict__ xs, int nlin, const double* __restrict__ x,
-                                  double* __restrict__ y) {
+// linear block, two deterministic passes (no floating-point atomics):
+//   t_l = xs_l * sum_i C[i,l] x_i   (by column);   y_i += sum_l C[i,l] t_l   (by row, CSR built at upload)
+__global__ void lin_t_kernel(const long* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
+                             const double* __restrict__ xs, int nlin, const double* __restrict__ x,
+                             double* __restrict__ tl) {
   int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= nlin) return;
   double t = 0.0;
   for (long k = ptr[l]; k < ptr[l + 1]; ++k) t += val[k] * x[row[k]];
-  t *= xs[l];
-  for (long k = ptr[l]; k < ptr[l + 1]; ++k) atomicAdd(&y[row[k]], val[k] * t);
+  tl[l] = t * xs[l];
 }
 
-__global__ void lin_diag_kernel(const long* __restrict__ ptr, const int* __restrict__ row, const double* __restrict__ val,
-                                const double* __restrict__ xs, int nlin, double* __restrict__ d) {
-  int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= nlin) return;
-  for (long k = ptr[l]; k < ptr[l + 1]; ++k) atomicAdd(&d[row[k]], val[k] * val[k] * xs[l]);
+__global__ void lin_rows_kernel(const long* __restrict__ rptr, const int* __restrict__ rcol,
+                                const double* __restrict__ rval, const double* __restrict__ tl, int n,
+                                double* __restrict__ y) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (long k = rptr[i]; k < rptr[i + 1]; ++k) s += rval[k] * tl[rcol[k]];
+  y[i] += s;
+}
+
+// d_i += sum_l C[i,l]^2 xs_l
+__global__ void lin_diag_kernel(const long* __restrict__ rptr, const int* __restrict__ rcol,
+                                const double* __restrict__ rval, const double* __restrict__ xs, int n,
+                                double* __restrict__ d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (long k = rptr[i]; k < rptr[i + 1]; ++k) s += rval[k] * rval[k] * xs[rcol[k]];
+  d[i] += s;
+}
+
+static int lin_matvec(lrn_ctx* c, const double* x, double* y) {
+  LRN_TRY(ensure(c, c->redbuf, (size_t)std::max(c->nlin, 64) * 8));
+  double* tl = c->redbuf.as<double>();
+  const unsigned gl = (unsigned)((c->nlin + 255) / 256), gn = (unsigned)((c->nvar + 255) / 256);
+  hipLaunchKernelGGL(lin_t_kernel, dim3(gl), dim3(256), 0, c->stream, c->cl_ptr.as<long>(), c->cl_rown.as<int>(),
+                     c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, x, tl);
+  hipLaunchKernelGGL(lin_rows_kernel, dim3(gn), dim3(256), 0, c->stream, c->cr_ptr.as<long>(), c->cr_col.as<int>(),
+                     c->cr_val.as<double>(), tl, c->nvar, y);
+  return LRN_OK;
 }
 
 
@@ -381,9 +406,7 @@ int matvec_dev(lrn_ctx* c, const double* x, double* y) {
     LRN_TRY(wmw(c, b, M, c->m1.as<double>(), c->m2.as<double>()));
     LRN_TRY(aa_times(c, b, c->m2.as<double>(), y));
   }
-  if (c->nlin > 0)
-    hipLaunchKernelGGL(lin_matvec_kernel, dim3(nb(c->nlin)), dim3(256), 0, c->stream, c->cl_ptr.as<long>(),
-                       c->cl_rown.as<int>(), c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, x, y);
+  if (c->nlin > 0) LRN_TRY(lin_matvec(c, x, y));
   LRN_HIP(c, hipGetLastError());
   return LRN_OK;
 }
@@ -428,9 +451,7 @@ int matvec_partial_dev(lrn_ctx* c, const double* x, double* y, int rank, int wor
       hipLaunchKernelGGL(aa_dense_dot_rows_kernel, dim3(b.nd), dim3(256), 0, c->stream, b.Adense.as<double>(), m,
                          c->m2.as<double>(), nr, r0, r1, b.sigma_d.as<int>(), y);
   }
-  if (c->nlin > 0 && rank == 0)
-    hipLaunchKernelGGL(lin_matvec_kernel, dim3(nb(c->nlin)), dim3(256), 0, c->stream, c->cl_ptr.as<long>(),
-                       c->cl_rown.as<int>(), c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, x, y);
+  if (c->nlin > 0 && rank == 0) LRN_TRY(lin_matvec(c, x, y));
   LRN_HIP(c, hipGetLastError());
   return LRN_OK;
 }
@@ -722,8 +743,8 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
     LRN_TRY(copy_out(c, &hd, c->info_dev.p, 4));
     if (hd != 0) { if (info) *info = hd; return LRN_OK; }
   } else if (c->nlin > 0)
-    hipLaunchKernelGGL(lin_diag_kernel, dim3(nb(c->nlin)), dim3(256), 0, st, c->cl_ptr.as<long>(), c->cl_rown.as<int>(),
-                       c->cl_val.as<double>(), c->lin_xs.as<double>(), c->nlin, P->d.as<double>());
+    hipLaunchKernelGGL(lin_diag_kernel, dim3(nb(n)), dim3(256), 0, st, c->cr_ptr.as<long>(), c->cr_col.as<int>(),
+                       c->cr_val.as<double>(), c->lin_xs.as<double>(), n, P->d.as<double>());
   if (kind == 1) {
     LRN_TRY(ensure(c, P->ts, (size_t)n * ksz * 8));
     int col0 = 0;

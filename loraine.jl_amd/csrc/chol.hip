@@ -24,9 +24,14 @@ static constexpr int NB = CHOL_NB;
 
 // ------------------------------------------------------------------ diagonal block
 // A (nb x nb, lower, ld) -> L in place (Linv: unused, kept for the signature).
+// diag0 != NULL (Schur matrix only): pivots at or below the rounding level of their original diagonal
+// entry, pivot <= boost * diag0[j] (zero and negative ones included), are replaced by a huge value --
+// the row drops out of the factor and the solves return 0 for it (the usual pivot boosting of
+// interior-point Cholesky codes).  info[1] counts them; more than `max_boost` is a failure.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, int ld, int nb,
                                                          double* __restrict__ Linv, int col0,
-                                                         int* __restrict__ info) {
+                                                         int* __restrict__ info, const double* __restrict__ diag0,
+                                                         double boost, int max_boost) {
   __shared__ double a[NB][NB + 1];
   __shared__ int bad;
   const int t = threadIdx.x;
@@ -41,6 +46,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A,
   // right-looking Cholesky: thread (ti, tg) owns row ti of the columns k == tg (mod 4)
   for (int j = 0; j < NB; ++j) {
     double piv = a[j][j];
+    if (diag0 && j < nb && piv <= boost * diag0[col0 + j] && piv == piv) {
+      piv = 1e40 * fmax(fabs(diag0[col0 + j]), 1.0);
+      if (t == 0 && atomicAdd(info + 1, 1) + 1 > max_boost) bad = col0 + j + 1;
+    }
     if (!(piv > 0.0)) {                          // also catches NaN; uniform across the workgroup
       if (t == 0) bad = col0 + j + 1;
       break;
@@ -178,6 +187,11 @@ __global__ void copy_panel_kernel(const double* __restrict__ src, int lds_, doub
 }
 
 int potrf_lower(hipStream_t st, double* A, int n, int ld, double* Linv, double* work, int* info_dev) {
+  return potrf_lower_boost(st, A, n, ld, Linv, work, info_dev, nullptr, 0.0, 0);
+}
+
+int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, double* work, int* info_dev,
+                      const double* diag0, double boost, int max_boost) {
   // work: n x NB doubles
   int nblk = (n + NB - 1) / NB;
   for (int b = 0; b < nblk; ++b) {
@@ -185,7 +199,7 @@ int potrf_lower(hipStream_t st, double* A, int n, int ld, double* Linv, double* 
     int nb = n - k0 < NB ? n - k0 : NB;
     double* Akk = A + (long)k0 + (long)k0 * ld;
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Akk, ld, nb,
-                       Linv + (long)b * NB * NB, k0, info_dev);
+                       Linv + (long)b * NB * NB, k0, info_dev, diag0, boost, max_boost);
     int rem = n - k0 - nb;
     if (rem <= 0) break;
     // panel: Wk = A21 * Lkk^-T      (rem x nb), by substitution

@@ -62,6 +62,11 @@ struct lrn_ctx {
   lrn::DBuf cl_ptr, cl_row, cl_val;   // int64 [nlin+1], int32 (Schur-matrix index), double
   lrn::DBuf cl_rown;                  // int32 natural row index
   lrn::DBuf lin_xs;                   // X_lin .* S_lin_inv  [nlin]
+  // deterministic gathers (no floating-point atomics): target entries of H with their contributions
+  // (C_lin diag(xs) C_lin' term), and C_lin by rows (mat-vec / diagonal of the linear term)
+  long lp_n = 0;                      // distinct lower-triangle targets
+  lrn::DBuf lp_r, lp_c, lp_ptr, lp_l, lp_w;   // int32 row, col (Schur index); int64 ptr; int32 l; double C[i,l]*C[j,l]
+  lrn::DBuf cr_ptr, cr_col, cr_val;   // CSR by natural row: int64 [nvar+1], int32 l, double
   // Schur complement
   lrn::DBuf H;          // assembled (lower triangle authoritative), nvar x nvar
   lrn::DBuf L;          // factor
@@ -69,6 +74,7 @@ struct lrn_ctx {
   lrn::DBuf cholwork;   // nvar * NB
   lrn::DBuf info_dev;   // int
   lrn::DBuf v0, v1, v2, v3;   // nvar-vectors (solve scratch)
+  lrn::DBuf hdiag;            // diag(H) before the factorisation (pivot boosting)
   bool have_H = false, have_L = false;
   // assembly workspaces
   lrn::DBuf P, T, slabs, Hd, BG;
@@ -82,7 +88,7 @@ struct lrn_ctx {
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // generic scratch
-  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lxbuf;
+  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lxbuf, ezbuf;
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
 };

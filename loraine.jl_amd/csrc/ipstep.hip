@@ -309,6 +309,69 @@ int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out) 
   return LRN_OK;
 }
 
+
+// ---- certified smallest eigenvalue
+// A Ritz value is only an UPPER bound of lambda_min, and plain Lanczos resolves the spectrum relative to
+// its spread: lambda_min = -1 next to eigenvalues of 1e6..1e10 (a poor direction after a regularised
+// Schur solve) comes back as -0.94 or even +9 -- the step-length rule (predictor_corrector.jl:272-291)
+// would then leave the cone.  Every estimate is therefore certified by one Cholesky test
+//   M - (theta - delta) I  positive definite  <=>  lambda_min > theta - delta,
+// and if the test fails lambda_min is bracketed by bisection over such tests (the reference calls a
+// dense `eigmin`; a positive-definiteness test is its GEMM-rich equivalent on this hardware).
+static int chol_shift_is_pd(lrn_ctx* c, const double* M, int n, double shift, bool* pd) {
+  hipStream_t st = c->stream;
+  LRN_TRY(ensure(c, c->info_dev, 64));
+  const size_t nn = (size_t)n * n;
+  LRN_TRY(ensure(c, c->ezbuf, (nn + (size_t)n * CHOL_NB + chol_linv_doubles(n) + 64) * 8));
+  double* F = c->ezbuf.as<double>();
+  double* work = F + nn;
+  double* linv = work + (size_t)n * CHOL_NB;
+  int* info = c->info_dev.as<int>() + 8;
+  LRN_HIP(c, hipMemcpyAsync(F, M, nn * 8, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(add_diag_mat_kernel, dim3((n + 255) / 256), dim3(256), 0, st, F, n, shift);
+  LRN_HIP(c, hipMemsetAsync(info, 0, 4, st));
+  LRN_TRY(potrf_lower(st, F, n, n, linv, work, info));
+  int h = 0;
+  LRN_TRY(copy_out(c, &h, info, 4));
+  *pd = h == 0;
+  c->counts["eigmin_chol_tests"] += 1;
+  return LRN_OK;
+}
+
+int eigmin_certified(lrn_ctx* c, const double* M, int n, double* lam) {
+  double theta = 0.0;
+  LRN_TRY(eigmin_dev(c, M, n, &theta, nullptr));
+  if (n == 1) { *lam = theta; return LRN_OK; }
+  bool pd = false;
+  if (theta > -1e-6) {
+    // callers only use the class "lambda_min > -1e-6" (step 0.99, DIMACS err2/err4 = 0)
+    LRN_TRY(chol_shift_is_pd(c, M, n, 1e-6, &pd));
+    if (pd) { *lam = theta; return LRN_OK; }
+  } else {
+    const double delta = 1e-7 * std::fabs(theta);
+    LRN_TRY(chol_shift_is_pd(c, M, n, delta - theta, &pd));
+    if (pd) { *lam = theta; return LRN_OK; }
+  }
+  // the Ritz value was not converged: bracket lambda_min in (lo, hi], hi = theta is an upper bound
+  c->counts["eigmin_bisections"] += 1;
+  double hi = theta, beta = std::max(2.0 * std::fabs(theta), 1.0);
+  for (int it = 0; it < 200; ++it) {
+    LRN_TRY(chol_shift_is_pd(c, M, n, beta, &pd));
+    if (pd) break;
+    hi = std::min(hi, -beta);
+    beta *= 4.0;
+  }
+  if (!pd) return set_error(c, LRN_ERR_STATE, "eigmin: matrix has no finite lower bound (NaN/Inf entries?)");
+  double lo = -beta;
+  for (int it = 0; it < 100 && hi - lo > 1e-9 * std::max(std::fabs(lo), 1e-6); ++it) {
+    const double mid = 0.5 * (lo + hi);
+    LRN_TRY(chol_shift_is_pd(c, M, n, -mid, &pd));
+    if (pd) lo = mid; else hi = mid;
+  }
+  *lam = lo;          // the safe side: slightly too negative shortens the step
+  return LRN_OK;
+}
+
 // ------------------------------------------------------------------ resident step
 static int ensure_resident(lrn_ctx* c, LmiBlock& b) {
   size_t mm_ = (size_t)b.msz * b.msz * 8;
@@ -477,11 +540,11 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
     LRN_TRY(mm(c, m, Gi, false, b.delX.as<double>(), false, t0));
     LRN_TRY(mm(c, m, t0, false, Gi, true, t1));
     hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t2, m);
-    LRN_TRY(eigmin_dev(c, t2, m, &lamX, nullptr));
+    LRN_TRY(eigmin_certified(c, t2, m, &lamX));
     LRN_TRY(mm(c, m, G, true, b.delS.as<double>(), false, t0));
     LRN_TRY(mm(c, m, t0, false, G, false, t1));
     hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t2, m);
-    LRN_TRY(eigmin_dev(c, t2, m, &lamS, nullptr));
+    LRN_TRY(eigmin_certified(c, t2, m, &lamS));
     alpha[il] = lamX > -1e-6 ? 0.99 : std::min(1.0, -tau / lamX);
     beta[il] = lamS > -1e-6 ? 0.99 : std::min(1.0, -tau / lamS);
   }
@@ -548,8 +611,8 @@ extern "C" int lrn_ip_stats(lrn_ctx* c, double* out5) {
   for (int il = 0; il < c->nlmi; ++il) {
     LmiBlock& b = c->lmi[il];
     double lx = 0, ls = 0;
-    LRN_TRY(eigmin_dev(c, b.X.as<double>(), b.msz, &lx, nullptr));
-    LRN_TRY(eigmin_dev(c, b.S.as<double>(), b.msz, &ls, nullptr));
+    LRN_TRY(eigmin_certified(c, b.X.as<double>(), b.msz, &lx));
+    LRN_TRY(eigmin_certified(c, b.S.as<double>(), b.msz, &ls));
     out5[5 * il + 1] = lx;
     out5[5 * il + 2] = ls;
     out5[5 * il + 3] = std::sqrt(out5[5 * il + 3]);
@@ -563,7 +626,7 @@ extern "C" int lrn_dbg_eigmin(lrn_ctx* c, int n, const double* M, double* lam, i
   DBuf d;
   LRN_TRY(ensure(c, d, (size_t)n * n * 8));
   LRN_TRY(copy_in(c, d.p, M, (size_t)n * n * 8));
-  int rc = eigmin_dev(c, d.as<double>(), n, lam, steps);
+  int rc = steps ? eigmin_dev(c, d.as<double>(), n, lam, steps) : eigmin_certified(c, d.as<double>(), n, lam);
   release(d);
   return rc;
 }

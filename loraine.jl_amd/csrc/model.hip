@@ -155,7 +155,8 @@ void lrn_free_model(lrn_ctx* c) {
   for (auto& b : c->lmi) free_block(b);
   c->lmi.clear();
   for (DBuf* d : {&c->cl_ptr, &c->cl_row, &c->cl_val, &c->lin_xs, &c->H, &c->L, &c->Linv, &c->cholwork,
-                  &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->T, &c->slabs, &c->Hd, &c->BG, &c->m0, &c->m1, &c->m2, &c->cgbuf, &c->cl_rown})
+                  &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->T, &c->slabs, &c->Hd, &c->BG, &c->m0, &c->m1, &c->m2, &c->cgbuf, &c->cl_rown,
+                  &c->hdiag, &c->lp_r, &c->lp_c, &c->lp_ptr, &c->lp_l, &c->lp_w, &c->cr_ptr, &c->cr_col, &c->cr_val})
     release(*d);
   c->P_cap = c->T_cap = 0;
   c->have_H = c->have_L = false;
@@ -415,6 +416,55 @@ extern "C" int lrn_upload_model(lrn_ctx* c, int nlmi, int nvar, const int64_t* m
     LRN_TRY(copy_in(c, c->cl_row.p, row.data(), (size_t)nn * 4));
     LRN_TRY(copy_in(c, c->cl_val.p, Clin_nzval, (size_t)nn * 8));
     LRN_TRY(ensure(c, c->lin_xs, (size_t)nlin * 8, true));
+    {  // gather lists: every lower-triangle target (ri >= rj) of C_lin diag(xs) C_lin' with its (l, C_il C_jl)
+      struct Con { int r, c, l; double w; };
+      std::vector<Con> cons;
+      for (int l = 0; l < nlin; ++l)
+        for (long a = ptr[l]; a < ptr[l + 1]; ++a)
+          for (long bq = ptr[l]; bq < ptr[l + 1]; ++bq)
+            if (row[a] >= row[bq]) cons.push_back({row[a], row[bq], l, Clin_nzval[a] * Clin_nzval[bq]});
+      std::stable_sort(cons.begin(), cons.end(), [](const Con& x, const Con& y) { return x.c != y.c ? x.c < y.c : x.r < y.r; });
+      std::vector<int> pr, pc, pl(cons.size());
+      std::vector<long> pp(1, 0);
+      std::vector<double> pw(cons.size());
+      for (size_t k = 0; k < cons.size(); ++k) {
+        if (k == 0 || cons[k].r != cons[k - 1].r || cons[k].c != cons[k - 1].c) {
+          if (k > 0) pp.push_back((long)k);
+          pr.push_back(cons[k].r); pc.push_back(cons[k].c);
+        }
+        pl[k] = cons[k].l; pw[k] = cons[k].w;
+      }
+      pp.push_back((long)cons.size());
+      c->lp_n = (long)pr.size();
+      LRN_TRY(ensure(c, c->lp_r, pr.size() * 4 + 4));
+      LRN_TRY(ensure(c, c->lp_c, pc.size() * 4 + 4));
+      LRN_TRY(ensure(c, c->lp_ptr, pp.size() * 8));
+      LRN_TRY(ensure(c, c->lp_l, pl.size() * 4 + 4));
+      LRN_TRY(ensure(c, c->lp_w, pw.size() * 8 + 8));
+      LRN_TRY(copy_in(c, c->lp_r.p, pr.data(), pr.size() * 4));
+      LRN_TRY(copy_in(c, c->lp_c.p, pc.data(), pc.size() * 4));
+      LRN_TRY(copy_in(c, c->lp_ptr.p, pp.data(), pp.size() * 8));
+      LRN_TRY(copy_in(c, c->lp_l.p, pl.data(), pl.size() * 4));
+      LRN_TRY(copy_in(c, c->lp_w.p, pw.data(), pw.size() * 8));
+      // C_lin by natural rows
+      std::vector<long> rp(nvar + 1, 0);
+      for (long k = 0; k < nn; ++k) rp[rown[k] + 1]++;
+      for (int i = 0; i < nvar; ++i) rp[i + 1] += rp[i];
+      std::vector<long> fill(rp.begin(), rp.end() - 1);
+      std::vector<int> rc(nn);
+      std::vector<double> rv(nn);
+      for (int l = 0; l < nlin; ++l)
+        for (long k = ptr[l]; k < ptr[l + 1]; ++k) {
+          long w = fill[rown[k]]++;
+          rc[w] = l; rv[w] = Clin_nzval[k];
+        }
+      LRN_TRY(ensure(c, c->cr_ptr, (size_t)(nvar + 1) * 8));
+      LRN_TRY(ensure(c, c->cr_col, (size_t)nn * 4 + 4));
+      LRN_TRY(ensure(c, c->cr_val, (size_t)nn * 8 + 8));
+      LRN_TRY(copy_in(c, c->cr_ptr.p, rp.data(), (size_t)(nvar + 1) * 8));
+      LRN_TRY(copy_in(c, c->cr_col.p, rc.data(), (size_t)nn * 4));
+      LRN_TRY(copy_in(c, c->cr_val.p, rv.data(), (size_t)nn * 8));
+    }
   }
   LRN_TRY(alloc_common(c));
   LRN_HIP(c, hipStreamSynchronize(c->stream));

@@ -336,8 +336,11 @@ class Device:
                                            C.byref(lmin), C.byref(tr), C.byref(st)), "lrn_dbg_lanczos")
         return lam[:k], U[:, :k], lmin.value, tr.value, st.value
 
-    def dbg_eigmin(self, M):
+    def dbg_eigmin(self, M, certified=False):
+        """certified=False: the plain Lanczos Ritz value and its step count; True: the Cholesky-certified
+        value the step-length rule and the DIMACS errors use (steps = 0)."""
         M = f64(M)
         lam = C.c_double(0.0); st = C.c_int(0)
-        self._chk(self.lib.lrn_dbg_eigmin(self.h, M.shape[0], ptr(M), C.byref(lam), C.byref(st)), "lrn_dbg_eigmin")
+        self._chk(self.lib.lrn_dbg_eigmin(self.h, M.shape[0], ptr(M), C.byref(lam), None if certified else C.byref(st)),
+                  "lrn_dbg_eigmin")
         return lam.value, st.value

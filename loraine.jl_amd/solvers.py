@@ -204,9 +204,10 @@ class MySolver:
         if self.regcount > 5:
             self.status = 3
             return False
-        for _ in range(1001):
+        for k in range(1001):
             self.dev.schur_add_diag(1e-4)
             if self.dev.schur_factor() == 0:
+                self.reg_adds = k + 1
                 return True
         self.status = 3
         return False
@@ -458,7 +459,10 @@ class MySolver:
                 gpu_ms=dict(prepare_w=d.timing("prepare_w"), assemble=d.timing("assemble"),
                             factor=d.timing("factor"), solve=d.timing("solve"),
                             prec_setup=d.timing("prec_setup"), pcg=d.timing("pcg"), svd=d.timing("prepw_svd")),
-                svd_sweeps=d.count("svd_sweeps"), find_step_ms=d.timing("find_step")))
+                svd_sweeps=d.count("svd_sweeps"), find_step_ms=d.timing("find_step"),
+                alpha=[float(a) for a in self.alpha] + [float(self.alpha_lin)],
+                beta=[float(b) for b in self.beta] + [float(self.beta_lin)], regcount=self.regcount,
+                reg_adds=getattr(self, "reg_adds", 0)))
             if time.perf_counter() - t1 > getattr(self, "time_budget", float("inf")):
                 self.status = 4            # tools/c5_solve.py: wall-clock cap for exploratory runs
             if self.preconditioner == 4:

@@ -57,6 +57,26 @@ def _run(path, resident, **opts):
     return o
 
 
+@pytest.mark.parametrize("n,hi", [(60, 1e2), (145, 1e6), (145, 1e10), (400, 1e8)])
+def test_certified_eigmin_on_wide_spectra(dev, n, hi):
+    """lambda_min = -1.005 next to eigenvalues up to `hi` (a direction after a regularised Schur solve,
+    tru9 iteration 28): plain Lanczos returns -0.94 or a positive value; the certified eigmin must not."""
+    rng = np.random.default_rng(n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([[-1.005], -np.exp(rng.uniform(np.log(1e-3), np.log(0.9), 5)),
+                          np.exp(rng.uniform(np.log(1e-3), np.log(hi), n - 6))])
+    M = (Q * lam) @ Q.T
+    M = 0.5 * (M + M.T)
+    exact = np.linalg.eigvalsh(M)[0]
+    got, _ = dev.dbg_eigmin(M, certified=True)
+    assert got <= exact + 1e-6 * abs(exact)          # never on the unsafe side by more than the tolerance
+    assert got == pytest.approx(exact, rel=1e-6, abs=1e-6 * hi * 1e-9)
+    # positive definite argument: only the class "> -1e-6" is promised
+    P = (Q * np.abs(lam)) @ Q.T
+    got, _ = dev.dbg_eigmin(0.5 * (P + P.T), certified=True)
+    assert got > -1e-6
+
+
 def test_theta1_resident_matches_oracle_trace():
     opts = dict(kit=0, eDIMACS=1e-6, initpoint=1, aamat=2)
     path = os.path.join(GOLD, "theta1.dat-s")
@@ -74,7 +94,7 @@ def test_theta1_resident_matches_oracle_trace():
     assert np.linalg.norm(o.solver.X[0] - ref.X[0]) <= 1e-6 * np.linalg.norm(ref.X[0])
 
 
-@pytest.mark.parametrize("name,opts", [("control1", dict(kit=0)), ("tru3", dict(kit=0)), ("vib3", dict(kit=0)),
+@pytest.mark.parametrize("name,opts", [("control1", dict(kit=0)), ("tru3", dict(kit=0)), ("vib3", dict(kit=0)), ("tru9", dict(kit=0)),
                                        ("maxG11", dict(kit=0, datarank=-1)),
                                        ("theta1", dict(kit=1, preconditioner=1, eDIMACS=1e-6, initpoint=1))])
 def test_resident_equals_host_driver(name, opts):

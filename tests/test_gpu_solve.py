@@ -80,3 +80,15 @@ def test_thetaG11_pcg_halpha():
     o = _run(os.path.join(GOLD, "thetaG11.dat-s"), kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
     assert o.termination_status() == "OPTIMAL"
     assert o.objective_value() == pytest.approx(400.0, rel=1e-4)
+
+
+@pytest.mark.parametrize("name,expected,iters", [("tru9", 0.0597530923, 28), ("vib9", 0.0127662873, 51)])
+def test_large_truss_problems(name, expected, iters):
+    """nvar = 3240 with 6480 linear rows and one / two LMI blocks (dense 3240^2 Schur matrix, C_lin
+    term of predictor_corrector.jl:33-37): same optimum and iteration count as the CPU oracle, whose
+    values are recorded in tests/golden/README.md."""
+    o = _run(os.path.join(GOLD, f"{name}.dat-s"), kit=0)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(expected, rel=2e-7)
+    assert abs(o.solver.iter - iters) <= 1
+    print(f"{name}: {o.solver.iter} iterations, {o.solver.tottime:.2f} s")

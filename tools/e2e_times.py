@@ -10,7 +10,8 @@ from oracle import loraine_oracle as lo
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 cases = [("theta1", dict(kit=0, eDIMACS=1e-6, initpoint=1, aamat=2), 0),
          ("maxG11", dict(kit=0, datarank=-1), -1),
-         ("thetaG11", dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5), 0)]
+         ("thetaG11", dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5), 0),
+         ("tru9", dict(kit=0), 0), ("vib9", dict(kit=0), 0)]
 only = [a for a in sys.argv[1:] if not a.startswith("--")]
 out = {}
 _dev = loraine_jl_amd.Device(0)
@@ -32,7 +33,7 @@ for name, opts, dr in cases:
     rec = dict(iters=its, obj=o.objective_value(), status=o.termination_status(), wall_s=tg,
                ms_per_iter_total=host_it, gpu_ms=g, cg_tot=o.solver.cg_iter_tot,
                svd_sweeps=[x["svd_sweeps"] for x in tr])
-    if "--cpu" in sys.argv or name != "thetaG11":
+    if "--cpu" in sys.argv or name in ("theta1", "maxG11"):
         t = time.perf_counter()
         s = lo.MySolver(lo.model_from_sdpa(path, datarank=dr), dict(opts, verb=0)); lo.solve(s)
         rec["cpu_wall_s"] = time.perf_counter() - t
