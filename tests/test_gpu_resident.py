@@ -187,3 +187,13 @@ def test_pcg_with_linear_rows(name, prec, erank):
     assert o.objective_value() == pytest.approx(lo.objective_value(ref), rel=2e-5, abs=1e-7)
     assert abs(o.solver.iter - ref.iter) <= 1
     assert abs(o.solver.cg_iter_tot - ref.cg_iter_tot) <= max(10, ref.cg_iter_tot // 5)
+
+
+@pytest.mark.parametrize("prec", [1, 2])
+def test_tru9_pcg_with_6480_linear_rows(prec):
+    """kit=1 at nvar = 3240, nlin = 6480: H_alpha factors the dense 3240^2 AAAATtau (Solvers.jl:743-745),
+    H_beta uses its diagonal.  Optimum from the kit=0 CPU oracle run (tests/golden/README.md)."""
+    o = _run(os.path.join(GOLD, "tru9.dat-s"), True, kit=1, preconditioner=prec, erank=1, eDIMACS=1e-5)
+    assert o.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(0.0597530923, rel=2e-5)
+    assert o.solver.cg_iter_tot > 0
