@@ -109,3 +109,14 @@ def test_pure_lp(resident):
     assert o.variable_primal()[0] == pytest.approx(2.0, rel=1e-6)
     lam = o.constraint_dual_lin()
     assert lam[0] == pytest.approx(0.0, abs=1e-6) and lam[1] == pytest.approx(2.0, rel=1e-6)
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_tiny_blocks(resident):
+    """Edge sizes: a 1x1 and a 2x2 LMI block, an empty constraint matrix in one block.
+        min y0 + y1   s.t.  [y0 - 1] >= 0,   [[y1, 1], [1, y1]] >= 0     ->  y = (1, 1), value 2"""
+    A1 = [sp.csc_matrix([[1.0]]), sp.csc_matrix([[1.0]]), sp.csc_matrix((1, 1))]          # F0 = 1, F1 = 1, F2 = 0
+    A2 = [sp.csc_matrix(-np.array([[0.0, 1.0], [1.0, 0.0]])), sp.csc_matrix((2, 2)), sp.identity(2, format="csc")]
+    o = _solve([A1, A2], -np.ones(2), None, None, False, resident)
+    assert o.objective_value() == pytest.approx(2.0, rel=1e-6)
+    assert o.variable_primal() == pytest.approx([1.0, 1.0], rel=1e-5)
