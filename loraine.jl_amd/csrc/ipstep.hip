@@ -12,6 +12,8 @@
 // steps; the host only bisects the tiny tridiagonal matrix.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/loraine_hip.h"
@@ -251,13 +253,17 @@ static double ritz_residual(const std::vector<double>& a, const std::vector<doub
   return std::fabs(b[m - 1] * s[m - 1]);
 }
 
-int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out) {
+int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, bool* converged = nullptr,
+               double* scale_out = nullptr) {
   hipStream_t st = c->stream;
+  if (converged) *converged = true;
+  if (scale_out) *scale_out = 0.0;
   if (n == 1) {
     LRN_TRY(copy_out(c, lam, M, 8));
     if (steps_out) *steps_out = 1;
     return LRN_OK;
   }
+  bool conv = false;
   // without re-orthogonalisation the extreme Ritz value may need more than n steps
   const int mmax = std::min(1500, 4 * n + 40);
   int nchunk = std::max(1, std::min(64, (int)(512 / std::max(1, (n + 255) / 256))));
@@ -294,21 +300,22 @@ int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out) 
     }
     theta = tridiag_min(a, b, mm_);
     m = m1;
-    if (mm_ < m1) break;
+    if (mm_ < m1) { conv = true; break; }
     // stop on the rigorous residual bound; for a clearly non-negative spectrum (theta > 0 is an
     // upper bound of lambda_min) the callers only need the sign class once theta has settled
     double res = ritz_residual(a, b, mm_, theta);
-    if (res <= 1e-11 * std::max(std::fabs(theta), 1e-4 * scale)) break;
+    if (res <= 1e-11 * std::max(std::fabs(theta), 1e-4 * scale)) { conv = true; break; }
     if (have_prev && theta > 0.0 && std::fabs(theta - theta_prev) <= 1e-3 * theta && m >= 64) break;
     theta_prev = theta;
     have_prev = true;
   }
   *lam = theta;
   if (steps_out) *steps_out = m;
+  if (converged) *converged = conv;
+  if (scale_out) *scale_out = scale;
   LRN_HIP(c, hipGetLastError());
   return LRN_OK;
 }
-
 
 // ---- certified smallest eigenvalue
 // A Ritz value is only an UPPER bound of lambda_min, and plain Lanczos resolves the spectrum relative to
@@ -339,9 +346,15 @@ static int chol_shift_is_pd(lrn_ctx* c, const double* M, int n, double shift, bo
 }
 
 int eigmin_certified(lrn_ctx* c, const double* M, int n, double* lam) {
-  double theta = 0.0;
-  LRN_TRY(eigmin_dev(c, M, n, &theta, nullptr));
+  double theta = 0.0, scale = 0.0;
+  bool conv = false;
+  LRN_TRY(eigmin_dev(c, M, n, &theta, nullptr, &conv, &scale));
+  static const bool trace = getenv("LRN_EIGMIN_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[eigmin n=%d] theta=%.12g conv=%d scale=%.3g\n", n, theta, (int)conv, scale);
   if (n == 1) { *lam = theta; return LRN_OK; }
+  // a Ritz value converged to 1e-11 on a spectrum of moderate spread (the usual O(1) scaled directions)
+  // needs no certificate: the failures are unconverged runs on spectra spanning 1e6 and more
+  if (conv && theta <= -1e-6 && scale <= 1e3 * std::fabs(theta)) { *lam = theta; return LRN_OK; }
   bool pd = false;
   if (theta > -1e-6) {
     // callers only use the class "lambda_min > -1e-6" (step 0.99, DIMACS err2/err4 = 0)
@@ -366,6 +379,7 @@ int eigmin_certified(lrn_ctx* c, const double* M, int n, double* lam) {
   for (int it = 0; it < 100 && hi - lo > 1e-9 * std::max(std::fabs(lo), 1e-6); ++it) {
     const double mid = 0.5 * (lo + hi);
     LRN_TRY(chol_shift_is_pd(c, M, n, -mid, &pd));
+    if (trace) fprintf(stderr, "   bisect mid=%.12g pd=%d\n", mid, (int)pd);
     if (pd) lo = mid; else hi = mid;
   }
   *lam = lo;          // the safe side: slightly too negative shortens the step
