@@ -266,8 +266,8 @@ int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, 
   bool conv = false;
   // without re-orthogonalisation the extreme Ritz value may need more than n steps
   const int mmax = std::min(1500, 4 * n + 40);
-  int nchunk = std::max(1, std::min(64, (int)(512 / std::max(1, (n + 255) / 256))));
-  nchunk = std::min(nchunk, std::max(1, n / 16));
+  // column chunks of the symmetric mat-vec: ~64 columns per thread keeps the step kernel's reduction short
+  int nchunk = std::max(1, std::min(64, n / 64));
   const int cper = (n + nchunk - 1) / nchunk;
   nchunk = (n + cper - 1) / cper;
   LRN_TRY(ensure(c, c->lzbuf, ((size_t)3 * n + (size_t)nchunk * n + 2 * (size_t)mmax + 64) * 8));
