@@ -138,7 +138,7 @@ int lrn_ip_rhs_pred(lrn_ctx* ctx, double* out);
 /* out = sum_i AA[i]*my_kron(G,G, G'RdG + D - sigma_mu./D - RNT)   (src/predictor_corrector.jl:186) */
 int lrn_ip_rhs_corr(lrn_ctx* ctx, double sigma_mu, double* out);
 /* delS, delX and the per-block step lengths alpha[nlmi], beta[nlmi]
- * (src/predictor_corrector.jl:248-291; eigmin by Lanczos on the device) */
+ * (src/predictor_corrector.jl:248-291; eigmin: Lanczos Ritz value, Cholesky-certified, on the device) */
 int lrn_ip_find_step(lrn_ctx* ctx, int predict, double sigma_mu, double tau, const double* dely,
                      double* alpha, double* beta);
 /* predict=1: Xn, Sn, RNT with the per-block steps, trXnSn[nlmi] returned (:302-311);

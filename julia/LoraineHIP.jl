@@ -157,4 +157,85 @@ function cg(ctx::Ctx, h::Vector{Float64}; tol::Float64, maxIter::Int = 10000)
     return x, Int(ec[]), Int(it[])
 end
 
+
+# ---- device-resident iterate (SURVEY.md 8f ranks 1-3): X, S, delX, delS, Xn, Sn, RNT never leave HBM ----
+# What loraine.jl_amd/resident.py does; only nvar-vectors and scalars cross the boundary.
+set_C!(ctx::Ctx, i::Int, C::Matrix{Float64}) =                      # once, C = -A[i,1]  (model.jl:133)
+    check(ctx, ccall((:lrn_ip_set_c, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), ctx.h, i - 1, C), "lrn_ip_set_c")
+set_iterate!(ctx::Ctx, i::Int, X::Matrix{Float64}, S::Matrix{Float64}) =   # initial_point.jl:33,42
+    check(ctx, ccall((:lrn_ip_set_iterate, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}), ctx.h, i - 1, X, S), "lrn_ip_set_iterate")
+function get_iterate(ctx::Ctx, i::Int, m::Int)                       # results: constraint duals, dual objective
+    X = Matrix{Float64}(undef, m, m); S = similar(X)
+    check(ctx, ccall((:lrn_ip_get_iterate, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}), ctx.h, i - 1, X, S), "lrn_ip_get_iterate")
+    return X, S
+end
+
+function prepare_W_resident!(ctx::Ctx, solver)                       # prepare_W.jl:5-94 incl. try_cholesky's loop
+    for i in 1:solver.model.nlmi
+        info = Ref{Cint}(0)
+        for _ in 1:1001
+            check(ctx, ccall((:lrn_ip_prepare_w, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}), ctx.h, i - 1, info), "lrn_ip_prepare_w")
+            info[] == 0 && break
+            check(ctx, ccall((:lrn_ip_add_diag, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cdouble), ctx.h, i - 1, info[], 1e-5), "lrn_ip_add_diag")
+        end
+    end
+end
+
+function residuals!(ctx::Ctx, solver)                                # predictor_corrector.jl:12-13
+    aax = Vector{Float64}(undef, solver.model.n)
+    check(ctx, ccall((:lrn_ip_aa_x, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, aax), "lrn_ip_aa_x")
+    check(ctx, ccall((:lrn_ip_residual_d, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, vec(solver.y)), "lrn_ip_residual_d")
+    solver.Rp = solver.model.b - aax            # minus C_lin * X_lin on the host when nlin > 0
+end
+
+function rhs_pred(ctx::Ctx, n::Int)                                  # makeRHS without Rp (makeBBBB.jl:221-228)
+    h = Vector{Float64}(undef, n)
+    check(ctx, ccall((:lrn_ip_rhs_pred, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, h), "lrn_ip_rhs_pred")
+    return h
+end
+function rhs_corr(ctx::Ctx, n::Int, sigma_mu::Float64)               # predictor_corrector.jl:186
+    h = Vector{Float64}(undef, n)
+    check(ctx, ccall((:lrn_ip_rhs_corr, LIB), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}), ctx.h, sigma_mu, h), "lrn_ip_rhs_corr")
+    return h
+end
+
+# find_step (predictor_corrector.jl:248-326): directions and per-block step lengths on the device; the scalar
+# rule  min([alpha; alpha_lin])  and the y / X_lin / S_lin updates stay in Julia
+function find_step!(ctx::Ctx, solver)
+    nl = solver.model.nlmi
+    alpha = Vector{Float64}(undef, nl); beta = similar(alpha)
+    check(ctx, ccall((:lrn_ip_find_step, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx.h, solver.predict ? 1 : 0, solver.sigma * solver.mu, solver.tau, vec(solver.dely), alpha, beta), "lrn_ip_find_step")
+    solver.alpha, solver.beta = alpha, beta
+    tr = Vector{Float64}(undef, nl)
+    if solver.predict
+        check(ctx, ccall((:lrn_ip_update, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx.h, 1, alpha, beta, tr), "lrn_ip_update")
+        return tr                                # tr(Xn Sn) per block for sigma_update (Solvers.jl:513-540)
+    end
+    a = [minimum([alpha; solver.alpha_lin])]; b = [minimum([beta; solver.beta_lin])]
+    check(ctx, ccall((:lrn_ip_update, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx.h, 0, a, b, tr), "lrn_ip_update")
+    solver.y .+= b[1] .* solver.dely
+    return tr
+end
+
+# per block: <X,S>, eigmin(X), eigmin(S), ||Rd||_F, <C,X>   (find_mu, check_convergence: Solvers.jl:480-511)
+function stats(ctx::Ctx, nlmi::Int)
+    out = Matrix{Float64}(undef, 5, nlmi)
+    check(ctx, ccall((:lrn_ip_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, out), "lrn_ip_stats")
+    return out
+end
+
+# ---- multi-GPU exchange (one process per GPU, e.g. MPI.jl ranks): SURVEY.md 8e -----------------
+set_shard!(ctx::Ctx, rank::Int, world::Int) =
+    check(ctx, ccall((:lrn_set_shard, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), ctx.h, rank, world), "lrn_set_shard")
+shard_doubles(ctx::Ctx) = ccall((:lrn_schur_shard_doubles, LIB), Int64, (Ptr{Cvoid},), ctx.h)
+# buf / buf_all are DEVICE pointers (ROCm-aware MPI_Allgather or RCCL between the two calls)
+export_shard!(ctx::Ctx, buf::Ptr{Float64}) =
+    check(ctx, ccall((:lrn_schur_export_shard, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, buf), "lrn_schur_export_shard")
+import_all!(ctx::Ctx, buf_all::Ptr{Float64}) =
+    check(ctx, ccall((:lrn_schur_import_all, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, buf_all), "lrn_schur_import_all")
+function matvec_partial!(ctx::Ctx, Ax::Vector{Float64}, x::Vector{Float64})   # caller all-reduces Ax
+    check(ctx, ccall((:lrn_matvec_partial, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, x, Ax), "lrn_matvec_partial")
+end
+
 end # module
