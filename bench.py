@@ -212,6 +212,13 @@ def main():
     elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    # the sharded path must leave the same solution on every rank (replicated factor + solves on the
+    # all-gathered matrix): compare a checksum of the corrector solve across ranks
+    chk = float(dely.double().sum().item())
+    if sharded:
+        chks = [None] * world
+        dist.all_gather_object(chks, chk)
+        assert all(c_ == chks[0] for c_ in chks), f"ranks disagree on dely: {chks}"
     if rank == 0:
         # dominant kernel: GEMM1  P_k = A_k W  (gemm_f64_kernel<128,128,...>, batched)
         n1 = max(1, dev.count("gemm1"))
@@ -240,12 +247,12 @@ def main():
                          "traffic": pmc_traffic_bytes() if (msz, world) == (2000, 1) else None,
                          "peak_probe": probe, "avg_launch_ms": t1, "launches_per_step": launches_per_step},
             "phase_ms_per_step": phases,
+            "dely_checksum": chk,
             "data_gen_s": t_gen,
         }
         if world == 1 and not args.no_cpu_baseline:
             dev.close()
             out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7)
-        # correctness guard for the sharded path: the solve must satisfy H x = h on the full matrix
         print(json.dumps(out), flush=True)
     if sharded:
         dist.barrier()
