@@ -224,7 +224,7 @@ def main():
         n1 = max(1, dev.count("gemm1"))
         t1 = dev.timing("gemm1") / n1                               # ms per launch (HIP events)
         from loraine_jl_amd.sharding import owned_columns
-        nown = len(owned_columns(nvar, rank, world))
+        nown = len(owned_columns(nvar, rank, world, bs=dev.shard_bs()))
         launches_per_step = n1 / args.steps
         units_per_launch = nown / launches_per_step                 # constraint matrices per launch
         alg_flops_launch = 2.0 * msz ** 3 * units_per_launch

@@ -61,7 +61,8 @@ int lrn_synthetic_dense_problem(lrn_ctx* ctx, uint64_t seed, double* b_out, doub
 /* dense copy of constraint matrix A_k (0-based k) of block ilmi, msz x msz */
 int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
 /* tuning knobs (process-wide): "dense_threshold" (nnz above which a branch-1 constraint takes
- * the MFMA path), "profile" (0/1), "t_batch", "p_batch", "shard_bs", "jacobi_warm" (0/1),
+ * the MFMA path), "profile" (0/1), "t_batch", "p_batch", "shard_bs" (0 = auto), "jacobi_warm" (0/1), "jacobi_block",
+ * "jacobi_inner", "jacobi_wgs", "pivot_boost" (relative pivot level boosted in lrn_schur_factor, 0 = off),
  * "prec_eig" (0 auto / 1 full Jacobi eigendecomposition / 2 Lanczos extremes in lrn_prec_setup),
  * "matvec_sparse" (0 auto / 1 dense GEMM mat-vec / 2 pattern-restricted mat-vec when every
  * constraint is sparse), "reset_timing". */
@@ -162,6 +163,8 @@ int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top
  * on the context's stream ("gemm1","gemm2","gemm3","sparse","assemble","factor","solve",...);
  * returns LRN_ERR_ARG for an unknown key. */
 int lrn_get_timing(lrn_ctx* ctx, const char* key, double* ms);
+/* launch / event counters of the same phases; "shard_bs" returns the column-block width of the Schur
+ * sharding in effect (option "shard_bs": 0 = auto, two 128-aligned blocks per rank) */
 int64_t lrn_get_count(lrn_ctx* ctx, const char* key);
 /* FP64 MFMA issue-rate probe (TFLOP/s of a register-only v_mfma_f64_16x16x4_f64 loop) */
 int lrn_mfma_f64_peak(lrn_ctx* ctx, double* tflops);

@@ -87,7 +87,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "jacobi_inner")) lrn::opt_jacobi_inner = (int)value;
   else if (!strcmp(key, "matvec_sparse")) lrn::opt_matvec_sparse = (int)value;
   else if (!strcmp(key, "jacobi_warm")) lrn::opt_jacobi_warm = value != 0.0;
-  else if (!strcmp(key, "shard_bs")) { if (value < 1) return LRN_ERR_ARG; c->shard_bs = (int)value; }
+  else if (!strcmp(key, "shard_bs")) { if (value < 0) return LRN_ERR_ARG; c->shard_bs_opt = (int)value; lrn::update_shard_bs(c); }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }
   else return set_error(c, LRN_ERR_ARG, "unknown option %s", key);
   return LRN_OK;
@@ -98,8 +98,10 @@ int lrn_set_shard(lrn_ctx* c, int rank, int world) {
   // the Schur column sharding needs position space (nlmi == 1); the row-sharded CG mat-vec does not
   c->rank = rank;
   c->world = world;
+  lrn::update_shard_bs(c);
   return LRN_OK;
 }
+
 
 int lrn_set_scaling(lrn_ctx* c, int il, const double* W, const double* G) {
   if (!c || il < 0 || il >= c->nlmi || !W) return LRN_ERR_ARG;
@@ -226,6 +228,7 @@ int lrn_get_timing(lrn_ctx* c, const char* key, double* ms) {
 
 int64_t lrn_get_count(lrn_ctx* c, const char* key) {
   if (!c || !key) return 0;
+  if (!strcmp(key, "shard_bs")) return c->shard_bs;      // state, not a per-call counter (survives reset_timing)
   auto it = c->counts.find(key);
   return it == c->counts.end() ? 0 : it->second;
 }

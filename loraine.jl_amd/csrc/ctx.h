@@ -51,6 +51,9 @@ struct LmiBlock {
   bool have_W = false, have_G = false;
 };
 
+struct lrn_ctx;
+namespace lrn { void update_shard_bs(lrn_ctx* c); }
+
 struct lrn_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -82,6 +85,7 @@ struct lrn_ctx {
   long P_cap = 0, T_cap = 0;   // capacity in matrices
   // shard (multi-GPU): this rank assembles owner columns with (pos / shard_bs) % world == rank
   int rank = 0, world = 1, shard_bs = 128;
+  int shard_bs_opt = 0;         // option "shard_bs": 0 = auto (see update_shard_bs)
   // timing of the last assembly / factor / solve (ms, HIP events on ctx stream)
   std::map<std::string, double> timing;
   std::map<std::string, long> counts;

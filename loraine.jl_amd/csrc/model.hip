@@ -51,6 +51,20 @@ bool is_device_ptr(const void* p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// Column-block width of the Schur sharding.  Auto: two blocks per rank (the snake map pairs a long early
+// block with a short late one, so two are enough to balance the triangle), rounded up to the 128-column
+// tile: the owner's GEMM3 then streams the constraint data twice instead of once per 128 columns.
+void update_shard_bs(lrn_ctx* c) {
+  int bs = 128;
+  if (c->shard_bs_opt > 0) bs = c->shard_bs_opt;
+  else if (c->world > 1 && c->nvar > 0) {
+    int per = (c->nvar + 2 * c->world - 1) / (2 * c->world);
+    bs = std::max(128, ((per + 127) / 128) * 128);
+  }
+  c->shard_bs = bs;
+  c->counts["shard_bs"] = bs;
+}
+
 int copy_in(lrn_ctx* c, void* dst, const void* src, size_t bytes) {
   if (bytes == 0) return LRN_OK;
   if (!src || !dst) return set_error(c, LRN_ERR_ARG, "copy_in: null pointer");
@@ -194,6 +208,7 @@ extern "C" int lrn_upload_model(lrn_ctx* c, int nlmi, int nvar, const int64_t* m
   lrn_free_model(c);
   c->nlmi = nlmi;
   c->nvar = nvar;
+  update_shard_bs(c);
   c->nlin = nlin;
   c->pos_space = (nlmi == 1);
   c->lmi.resize(nlmi);
@@ -477,6 +492,7 @@ extern "C" int lrn_synthetic_dense_model(lrn_ctx* c, int msz, int nvar, uint64_t
   lrn_free_model(c);
   c->nlmi = 1;
   c->nvar = nvar;
+  update_shard_bs(c);
   c->nlin = 0;
   c->pos_space = true;
   c->lmi.resize(1);

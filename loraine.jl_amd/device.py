@@ -45,6 +45,10 @@ class Device:
     def set_option(self, key, value):
         self._chk(self.lib.lrn_set_option(self.h, key.encode(), float(value)), f"set_option({key})")
 
+    def shard_bs(self):
+        """column-block width of the Schur sharding in effect (auto: two blocks per rank, multiple of 128)"""
+        return int(self.count("shard_bs"))
+
     def set_shard(self, rank, world):
         self._chk(self.lib.lrn_set_shard(self.h, int(rank), int(world)), "set_shard")
 

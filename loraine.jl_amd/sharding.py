@@ -14,6 +14,15 @@ import numpy as np
 SHARD_BS = 128
 
 
+def auto_bs(nvar, world):
+    """Block width the C library picks when the option "shard_bs" is 0 (update_shard_bs in csrc/model.hip):
+    two blocks per rank, rounded up to the 128-column tile."""
+    if world <= 1 or nvar <= 0:
+        return SHARD_BS
+    per = (nvar + 2 * world - 1) // (2 * world)
+    return max(SHARD_BS, ((per + 127) // 128) * 128)
+
+
 def geometry(nvar, world, bs=SHARD_BS):
     nblk = (nvar + bs - 1) // bs
     bpr = (nblk + world - 1) // world

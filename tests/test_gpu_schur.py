@@ -186,7 +186,7 @@ def test_shard_export_import_roundtrip(dev):
     dev.schur_import_all(allbuf)              # geometry of the 2-rank exchange
     H2 = dev.schur_get()
     dev.set_shard(0, 1)
-    dev.set_option("shard_bs", 128)
+    dev.set_option("shard_bs", 0)             # back to auto
     # the C library's exchange layout is the one loraine.jl_amd/sharding.py specifies
     from loraine_jl_amd import sharding
     sig = model.sigmaA[:, 0]
@@ -211,6 +211,8 @@ def test_rank1_sharded_columns(dev):
     parts = []
     for r in range(3):
         dev.set_shard(r, 3)
+        from loraine_jl_amd import sharding as _sh
+        assert dev.shard_bs() == _sh.auto_bs(model.n, 3)       # the C rule and its Python specification agree
         dev.schur_assemble(-1)
         buf = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
         dev.schur_export_shard(buf)
