@@ -53,11 +53,14 @@ def pmc_traffic_bytes():
     import csv
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.csv"))):
         vals = {}
-        for r in csv.DictReader(open(f)):
-            if "gemm_f64_lds_kernel<false>" in r["kernel"] and r["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals[r["counter"]] = float(r["mean"])
+        try:
+            for r in csv.DictReader(open(f)):
+                if "gemm_f64_lds_kernel<false>" in r.get("kernel", "") and r.get("counter") in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[r["counter"]] = float(r["mean"])
+        except (OSError, ValueError, KeyError):      # a malformed summary must never take the bench line down
+            continue
         if len(vals) == 2:
             best = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     return best
