@@ -4,6 +4,9 @@ The product path has NO CPU fallback: if the shared library is missing, or no GP
 visible when a context is created, this raises."""
 import ctypes as C
 import os
+import shutil
+import subprocess
+import sys
 
 import numpy as np
 
@@ -88,6 +91,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and shutil.which("hipcc") and os.environ.get("LRN_NO_AUTOBUILD") is None:
+        # a fresh checkout on a box with the ROCm toolchain: compile the HIP sources once (this is the
+        # product library itself, not a fallback)
+        csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+        print(f"[loraine.jl_amd] {LIB_PATH} missing: running `make -C {csrc}` (hipcc --offload-arch=gfx950)",
+              file=sys.stderr, flush=True)
+        subprocess.run(["make", "-C", csrc, "-j8"], check=False, stdout=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise LoraineHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
