@@ -24,7 +24,7 @@ for kv in filter(None, os.environ.get("LRN_OPTS", "").split(",")):      # e.g. L
     k, v = kv.split("=")
     dev.set_option(k, float(v))
 t0 = time.perf_counter()
-opts = dict(kit=1, preconditioner=prec, erank=rank, verb=1, maxit=maxit, eDIMACS=float(os.environ.get("C5_EDIMACS", "1e-5")),
+opts = dict(kit=int(os.environ.get("C5_KIT", "1")), preconditioner=prec, erank=rank, verb=1, maxit=maxit, eDIMACS=float(os.environ.get("C5_EDIMACS", "1e-5")),
             tol_cg_min=float(os.environ.get("C5_TOL_CG_MIN", "1e-7")))
 solver, ha = resident.load(model, opts, device=dev)
 print("generate %.1f s, upload %.1f s" % (t_gen, time.perf_counter() - t0), flush=True)
