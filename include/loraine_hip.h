@@ -155,6 +155,11 @@ int lrn_dbg_eigmin(lrn_ctx* ctx, int n, const double* M, double* lam, int* steps
 /* k largest eigenpairs (ascending; U_top n x k column-major, may be NULL), smallest eigenvalue and
  * trace of a symmetric matrix: what the preconditioner setup consumes of `eigen(W)`
  * (src/Solvers.jl:642-650,706-722); unit test of the Lanczos path (option "prec_eig") */
+/* approximate eigenvectors V (orthogonal, V'KV nearly diagonal) of a symmetric positive definite K by
+ * spectral divide and conquer (QDWH sign function + CholeskyQR2; the large-msz starting basis of
+ * lrn_prepare_w when option "svd_sdc" is on); lrn_get_count keys sdc_splits, sdc_leaves, sdc_qdwh_its,
+ * sdc_fallbacks */
+int lrn_dbg_sdc(lrn_ctx* ctx, int n, const double* K, double* V);
 int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top, double* U_top,
                     double* lam_min, double* trace, int* steps);
 

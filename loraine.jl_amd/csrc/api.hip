@@ -17,6 +17,8 @@ extern int opt_matvec_sparse;
 extern int opt_jacobi_inner;
 extern int opt_jacobi_block;
 extern int opt_jacobi_wgs;
+extern int opt_svd_sdc, opt_sdc_min, opt_sdc_leaf;
+extern double opt_sdc_l0;
 extern double opt_pivot_boost;
 }
 
@@ -65,6 +67,7 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->lzbuf);
   release(c->lxbuf);
   release(c->ezbuf);
+  release(c->sdcbuf);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -82,6 +85,10 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
   else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
   else if (!strcmp(key, "pivot_boost")) lrn::opt_pivot_boost = value;
+  else if (!strcmp(key, "svd_sdc")) lrn::opt_svd_sdc = (int)value;
+  else if (!strcmp(key, "sdc_min")) lrn::opt_sdc_min = (int)value;
+  else if (!strcmp(key, "sdc_leaf")) lrn::opt_sdc_leaf = (int)value;
+  else if (!strcmp(key, "sdc_l0")) lrn::opt_sdc_l0 = value;
   else if (!strcmp(key, "jacobi_wgs")) lrn::opt_jacobi_wgs = (int)value;
   else if (!strcmp(key, "jacobi_block")) lrn::opt_jacobi_block = (int)value;
   else if (!strcmp(key, "jacobi_inner")) lrn::opt_jacobi_inner = (int)value;

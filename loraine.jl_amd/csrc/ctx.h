@@ -92,7 +92,7 @@ struct lrn_ctx {
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // generic scratch
-  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lxbuf, ezbuf;
+  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lxbuf, ezbuf, sdcbuf;
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
 };
