@@ -65,7 +65,9 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * "jacobi_inner", "jacobi_wgs", "pivot_boost" (relative pivot level boosted in lrn_schur_factor, 0 = off),
  * "prec_eig" (0 auto / 1 full Jacobi eigendecomposition / 2 Lanczos extremes in lrn_prec_setup),
  * "matvec_sparse" (0 auto / 1 dense GEMM mat-vec / 2 pattern-restricted mat-vec when every
- * constraint is sparse), "reset_timing". */
+ * constraint is sparse), "svd_sdc" (0/1,
+ * experimental divide-and-conquer start of the SVD for msz >= "sdc_min"; "sdc_leaf", "sdc_l0"),
+ * "reset_timing". */
 int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
 /* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */
 int lrn_set_shard(lrn_ctx* ctx, int rank, int world);
