@@ -144,6 +144,38 @@ __global__ void k_rt_minus(const double* __restrict__ R, int n, int k, int k2, d
   }
 }
 
+// y = (K - sigma I) x, one workgroup per 64 rows (K symmetric: column access is coalesced)
+__global__ __launch_bounds__(256) void k_symv_shift(const double* __restrict__ K, int n, double sigma,
+                                                    const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (i < n)
+    for (int j = w; j < n; j += 4) s += K[(long)i + (long)j * n] * x[j];
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < n) y[i] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] - sigma * x[i];
+}
+
+// x <- y / ||y||, nrm[0] = ||y||     (single workgroup)
+__global__ __launch_bounds__(1024) void k_normalize(const double* __restrict__ y, int n, double* __restrict__ x,
+                                                    double* __restrict__ nrm) {
+  __shared__ double sh[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += y[i] * y[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < 16; ++i) t += sh[i];
+  t = sqrt(t);
+  const double r = t > 0.0 ? 1.0 / t : 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) x[i] = y[i] * r;
+  if (threadIdx.x == 0) nrm[0] = t;
+}
+
 int GM(hipStream_t st, int M, int N, int K, const double* A, long sAm, long sAk, const double* B, long sBk, long sBn,
        double* C, long sCm, long sCn, double alpha = 1.0, double beta = 0.0, int flags = 0) {
   GemmDesc g;
@@ -250,6 +282,22 @@ int sdc_rec(lrn_ctx* c, double* K, int n, double* V, Bump& bump, const Work& w, 
   double alpha = 0.0;
   for (int j = 0; j < n; ++j) alpha = std::max(alpha, hd[n + j] + std::fabs(sigma));
   if (!(alpha > 0.0) || !std::isfinite(alpha)) return leaf_jacobi(c, K, n, V, w);
+  {
+    // the 1-norm overestimates ||K - sigma I||_2 by up to sqrt(n) -- on the clustered spectra of centred
+    // iterates by 50x --, which costs QDWH steps: 12 power iterations give the 2-norm (x1.2 for safety;
+    // the 1-norm stays the hard upper bound)
+    double* xv = w.vec;
+    double* yv = w.vec + n;
+    hipLaunchKernelGGL(k_rand, dim3(nbl(n)), dim3(256), 0, st, yv, (long)n, (unsigned)(7 + depth));
+    double nrm = 0.0;
+    for (int it = 0; it < 12; ++it) {
+      hipLaunchKernelGGL(k_normalize, dim3(1), dim3(1024), 0, st, yv, n, xv, w.vec + 2 * (size_t)n);
+      hipLaunchKernelGGL(k_symv_shift, dim3((n + 63) / 64), dim3(256), 0, st, K, n, sigma, xv, yv);
+    }
+    hipLaunchKernelGGL(k_normalize, dim3(1), dim3(1024), 0, st, yv, n, xv, w.vec + 2 * (size_t)n);
+    LRN_TRY(copy_out(c, &nrm, w.vec + 2 * (size_t)n, 8));
+    if (nrm > 0.0 && std::isfinite(nrm)) alpha = std::min(alpha, 1.2 * nrm);
+  }
   // persistent over the recursion: the two bases, the children's matrices and eigenvectors;
   // transient (released before recursing): X, Z, Y
   double* Qt = bump.take((size_t)nn + 64);
@@ -337,7 +385,7 @@ int sdc_rec(lrn_ctx* c, double* K, int n, double* V, Bump& bump, const Work& w, 
 // K (n x n, symmetric positive definite, destroyed) -> V (n x n): orthogonal, V' K V nearly diagonal
 int sdc_eig(lrn_ctx* c, double* K, int n, double* V) {
   const size_t nn = (size_t)n * n;
-  const size_t work = (size_t)2 * n * CHOL_NB + 2 * (size_t)n + 256;
+  const size_t work = (size_t)2 * n * CHOL_NB + 2 * (size_t)n + 512;
   LRN_TRY(ensure(c, c->sdcbuf, (8 * nn + work + 65536) * 8));
   LRN_TRY(ensure(c, c->info_dev, 64));
   double* base = c->sdcbuf.as<double>();
