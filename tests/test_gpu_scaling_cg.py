@@ -372,3 +372,30 @@ def test_prepare_w_with_sdc_start(dev):
     assert relerr(out["W"], base["W"]) < 1e-10
     assert relerr(out["W"] @ S @ out["W"], X) < 1e-9
     assert np.allclose(np.sort(out["D"]), np.sort(base["D"]), rtol=1e-10)
+
+
+def test_partial_matvec_two_blocks_with_linear_rows(dev):
+    """kit=1 multi-GPU operator on vib3 (two LMI blocks, 72 linear rows): the partial mat-vecs of a 4-way
+    sharding add up to MyA(x); the C_lin term is contributed by rank 0 only."""
+    from loraine_jl_amd._capi import ptr
+    model = lo.model_from_sdpa(os.path.join(GOLD, "vib3.dat-s"))
+    s = _iterate(model, dict(kit=0), 4)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes, C_lin=model.C_lin)
+    for i in range(model.nlmi):
+        dev.set_scaling(i, s.W[i], s.G[i])
+    dev.set_lin(s.X_lin, s.S_lin_inv)
+    x = np.random.default_rng(5).standard_normal(model.n)
+    full = dev.matvec(x)
+    ref = np.zeros(model.n)
+    lo.MyA(s.W, model.AA, model.nlin, model.C_lin, s.X_lin, s.S_lin_inv)(ref, x)
+    assert relerr(full, ref) < 1e-12
+    acc = np.zeros(model.n)
+    try:
+        for r in range(4):
+            dev.set_shard(r, 4)
+            part = np.zeros(model.n)
+            dev._chk(dev.lib.lrn_matvec_partial(dev.h, ptr(x), ptr(part)), "lrn_matvec_partial")
+            acc += part
+    finally:
+        dev.set_shard(0, 1)
+    assert relerr(acc, ref) < 1e-12
