@@ -55,7 +55,9 @@ __global__ __launch_bounds__(64) void potrf_diag_wave_kernel(double* __restrict_
       double piv = readlane_f64(a[j], j);
       if (diag0 && j < nb) {
         const double d0 = diag0[col0 + j];
-        if (piv <= boost * d0 && piv == piv) {
+        // d0 > 0: a structurally empty row (a variable that occurs in no constraint) is not rounding noise;
+        // it fails like in the reference, whose +1e-4 I loop and regularisation count then decide
+        if (d0 > 0.0 && piv <= boost * d0 && piv == piv) {
           piv = 1e40 * fmax(fabs(d0), 1.0);
           int cnt = 0;
           if (i == 0) cnt = atomicAdd(info + 1, 1) + 1;

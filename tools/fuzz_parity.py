@@ -1,0 +1,85 @@
+"""Randomised end-to-end parity: small random SDPs (several LMI blocks of different sizes, dense and sparse
+constraint matrices, empty ones, linear rows) solved by the GPU path (both drivers, kit 0 and 1) and by the
+CPU oracle; reports any disagreement in status, iteration count (+-1) or objective (1e-6 relative)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, scipy.sparse as sp
+from loraine_jl_amd.optimizer import Optimizer
+from oracle import loraine_oracle as lo
+
+def random_problem(rng):
+    nvar = int(rng.integers(3, 14))
+    nblk = int(rng.integers(1, 4))
+    sizes = [int(rng.integers(1, 9)) for _ in range(nblk)]
+    y0 = rng.standard_normal(nvar)
+    A = []
+    for m in sizes:
+        blk = [None]
+        for k in range(nvar):
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                M = np.zeros((m, m))                                   # empty constraint matrix
+            elif kind == 1:
+                M = np.zeros((m, m)); i, j = rng.integers(0, m, 2); v = rng.standard_normal(); M[i, j] += v; M[j, i] += v
+            else:
+                R = rng.standard_normal((m, m)) * (rng.random((m, m)) < (0.3 if kind == 2 else 1.0)); M = R + R.T
+            blk.append(sp.csc_matrix(M))
+        S0 = rng.standard_normal((m, m)); S0 = S0 @ S0.T + np.eye(m)      # strictly feasible slack at y0
+        F0 = sum(y0[k] * blk[k + 1].toarray() for k in range(nvar)) - S0
+        blk[0] = sp.csc_matrix(F0)
+        A.append(blk)
+    nlin = int(rng.integers(0, 5))
+    C_lin = d_lin = None
+    if nlin:
+        Cl = rng.standard_normal((nvar, nlin)) * (rng.random((nvar, nlin)) < 0.6)
+        d_lin = Cl.T @ y0 + rng.random(nlin) + 0.1                       # C_lin' y0 < d_lin
+        C_lin = sp.csr_matrix(Cl)
+    # bounded: b = A*(X0) with X0 > 0  (+ linear part)
+    b = np.zeros(nvar)
+    for blk, m in zip(A, sizes):
+        X0 = rng.standard_normal((m, m)); X0 = X0 @ X0.T + np.eye(m)
+        b += np.array([-(blk[k + 1].multiply(X0)).sum() for k in range(nvar)]) * -1.0
+    if nlin:
+        b += C_lin @ (rng.random(nlin) + 0.1)
+    return A, b, d_lin, C_lin
+
+def main():
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    bad = 0
+    t0 = time.time()
+    for s in range(seed0, seed0 + count):
+        rng = np.random.default_rng(s)
+        A, b, d_lin, C_lin = random_problem(rng)
+        kits = (dict(kit=0),) if os.environ.get("FUZZ_KIT1") is None else (
+            dict(kit=0), dict(kit=1, preconditioner=2, eDIMACS=1e-6), dict(kit=1, preconditioner=1, eDIMACS=1e-6))
+        for opts in kits:
+            if opts["kit"] == 1 and (opts["preconditioner"] == 1 and C_lin is not None and False):
+                continue
+            try:
+                om = lo.make_model([[m.copy() for m in blk] for blk in A], b.copy(), 0.0,
+                                   None if d_lin is None else d_lin.copy(), None if C_lin is None else C_lin.copy())
+                ref = lo.MySolver(om, dict(opts, verb=0)); lo.solve(ref)
+                rs, ro, ri = ref.status, lo.objective_value(ref), ref.iter
+            except Exception as e:
+                rs, ro, ri = "exc:" + type(e).__name__, None, None
+            for resident in (True, False):
+                o = Optimizer(resident=resident); o.set_silent(True)
+                for k, v in opts.items(): o.set_attribute(k, v)
+                o.load_model([[m.copy() for m in blk] for blk in A], b.copy(), 0.0, d_lin, C_lin, max_sense=False)
+                try:
+                    o.optimize(); gs, go, gi = o.solver.status, o.objective_value(), o.solver.iter
+                except Exception as e:
+                    gs, go, gi = "exc:" + type(e).__name__, None, None
+                # status must agree; objective and iteration count are compared for solved problems only
+                ok = gs == rs and (rs != 1 or (abs(go - ro) <= 1e-6 * (1 + abs(ro)) and abs(gi - ri) <= 1))
+                if not ok:
+                    bad += 1
+                    print(f"MISMATCH seed {s} {opts} resident={resident}: gpu ({gs}, {go}, {gi}) vs oracle ({rs}, {ro}, {ri})", flush=True)
+        if (s - seed0) % 5 == 4:
+            print(f"... {s - seed0 + 1} problems, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {count} problems x {len(kits)} option sets x 2 drivers, {bad} mismatches")
+    return 1 if bad else 0
+
+if __name__ == "__main__":
+    sys.exit(main())
