@@ -81,8 +81,8 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   if (!c || !key) return LRN_ERR_ARG;
   if (!strcmp(key, "dense_threshold")) lrn_opt_dense_threshold = value;
   else if (!strcmp(key, "profile")) c->profile = value != 0.0;
-  else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); c->T_cap = c->P_cap = 0; }
-  else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); c->T_cap = c->P_cap = 0; }
+  else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); for (auto& b : c->lmi) b.t_cap = b.p_cap = 0; }
+  else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); for (auto& b : c->lmi) b.t_cap = b.p_cap = 0; }
   else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
   else if (!strcmp(key, "pivot_boost")) lrn::opt_pivot_boost = value;
   else if (!strcmp(key, "svd_sdc")) lrn::opt_svd_sdc = (int)value;
@@ -220,6 +220,7 @@ int lrn_schur_import_all(lrn_ctx* c, const double* buf_all) {
     }
   LRN_HIP(c, hipStreamSynchronize(c->stream));
   c->have_H = true;
+  c->H_shifted = false;
   c->have_L = false;
   return LRN_OK;
 }

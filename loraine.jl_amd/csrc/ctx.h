@@ -18,6 +18,7 @@ struct LmiBlock {
   int nd = 0;               // positions [0,nd): T_i = W A_i W by MFMA GEMM, A stored dense
   int q_wave = 0;           // positions [nd,q_wave): wave-per-pair kernel; [q_wave,n): thread-per-pair
   int npos_nz = 0;          // positions with nnz > 0 form the prefix [0,npos_nz)
+  long p_cap = 0, t_cap = 0; // batch capacities (matrices) of the P / T workspaces for this block
   lrn::DBuf ent_ptr;        // int64 [nvar+1]
   lrn::DBuf ent_r, ent_c;   // int32 [nent]
   lrn::DBuf ent_v;          // double [nent]   value of A_j (= -AA)
@@ -79,10 +80,12 @@ struct lrn_ctx {
   lrn::DBuf v0, v1, v2, v3;   // nvar-vectors (solve scratch)
   lrn::DBuf hdiag;            // diag(H) before the factorisation (pivot boosting)
   bool have_H = false, have_L = false;
+  bool H_shifted = false;     // lrn_schur_add_diag since the last assembly: strict Cholesky only
   // assembly workspaces
   lrn::DBuf P, T, slabs, Hd, BG;
   lrn::DBuf m0, m1, m2, cgbuf;   // msz^2 work matrices (mat-vec / rhs), PCG vectors
-  long P_cap = 0, T_cap = 0;   // capacity in matrices
+  int T_m = 0;                 // matrix side and block the T workspace was last laid out for
+  const void* T_owner = nullptr;
   // shard (multi-GPU): this rank assembles owner columns with (pos / shard_bs) % world == rank
   int rank = 0, world = 1, shard_bs = 128;
   int shard_bs_opt = 0;         // option "shard_bs": 0 = auto (see update_shard_bs)

@@ -172,7 +172,8 @@ void lrn_free_model(lrn_ctx* c) {
                   &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->T, &c->slabs, &c->Hd, &c->BG, &c->m0, &c->m1, &c->m2, &c->cgbuf, &c->cl_rown,
                   &c->hdiag, &c->lp_r, &c->lp_c, &c->lp_ptr, &c->lp_l, &c->lp_w, &c->cr_ptr, &c->cr_col, &c->cr_val})
     release(*d);
-  c->P_cap = c->T_cap = 0;
+  c->T_m = 0;
+  c->T_owner = nullptr;
   c->have_H = c->have_L = false;
   c->nlmi = c->nvar = c->nlin = 0;
 }

@@ -256,21 +256,29 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   double* W = b.W.as<double>();
   double* Ad = b.Adense.as<double>();
   double* H = c->H.as<double>();
-  // capacities
-  if (c->T_cap == 0 || c->P_cap == 0) {
+  // capacities, per block: blocks of one problem differ in size (a cache keyed on the context once sized
+  // the P / T workspaces for the first block and let a larger later block write past them)
+  if (b.t_cap == 0 || b.p_cap == 0) {
     size_t free_b = 0, total_b = 0;
     LRN_HIP(c, hipMemGetInfo(&free_b, &total_b));
     long pcap = opt_p_batch > 0 ? opt_p_batch : pick_p_batch(m, nd);
     if (pcap > nd) pcap = nd;
-    double avail = (double)free_b * 0.80 - (double)pcap * mm * 8.0 - 1.5e9;
+    // memory that is free now plus what the shared workspaces already hold
+    double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes) * 0.80 - (double)pcap * mm * 8.0 - 1.5e9;
     long tcap = (long)(avail / ((double)mm * 8.0));
     if (opt_t_batch > 0) tcap = opt_t_batch;
     if (tcap > nd) tcap = nd;
     if (tcap < 1) return set_error(c, LRN_ERR_NOMEM, "not enough device memory for the T workspace");
-    LRN_TRY(ensure(c, c->P, (size_t)pcap * mm * 8));
-    LRN_TRY(ensure(c, c->T, (size_t)tcap * mm * 8, true));   // upper tiles stay zero forever
-    c->P_cap = pcap;
-    c->T_cap = tcap;
+    b.p_cap = pcap;
+    b.t_cap = tcap;
+  }
+  const long P_cap = b.p_cap, T_cap = b.t_cap;
+  LRN_TRY(ensure(c, c->P, (size_t)P_cap * mm * 8));
+  LRN_TRY(ensure(c, c->T, (size_t)T_cap * mm * 8, true));   // upper tiles stay zero between assemblies ...
+  if (c->T_m != m || c->T_owner != &b) {                    // ... of the SAME block: another layout left its data
+    LRN_HIP(c, hipMemsetAsync(c->T.p, 0, (size_t)T_cap * mm * 8, c->stream));
+    c->T_m = m;
+    c->T_owner = &b;
   }
   double* P = c->P.as<double>();
   double* T = c->T.as<double>();
@@ -289,15 +297,15 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
     for (int s0 = 0; s0 < nd; s0 += c->shard_bs)
       if (shard_owner(s0 / c->shard_bs, c->world) == c->rank) {
         int s1 = std::min(nd, s0 + c->shard_bs);
-        for (int a = s0; a < s1; a += (int)c->T_cap) groups.push_back({a, std::min(s1, a + (int)c->T_cap)});
+        for (int a = s0; a < s1; a += (int)T_cap) groups.push_back({a, std::min(s1, a + (int)T_cap)});
       }
   } else {
-    for (int s0 = 0; s0 < nd; s0 += (int)c->T_cap) groups.push_back({s0, std::min(nd, s0 + (int)c->T_cap)});
+    for (int s0 = 0; s0 < nd; s0 += (int)T_cap) groups.push_back({s0, std::min(nd, s0 + (int)T_cap)});
   }
   for (auto& g : groups) {
     const int s0 = g.first, s1 = g.second, ns = s1 - s0;
-    for (int a = s0; a < s1; a += (int)c->P_cap) {
-      int nb = std::min((int)c->P_cap, s1 - a);
+    for (int a = s0; a < s1; a += (int)P_cap) {
+      int nb = std::min((int)P_cap, s1 - a);
       tic(c);
       GemmDesc g1;   // P = A_a W, stored row-major (P^T) so that GEMM2 reads it n-contiguous;
                      // W is symmetric, so it is read as W[n + k*m]: both operands stream
@@ -462,6 +470,7 @@ int schur_assemble(lrn_ctx* c, int mode) {
   }
   LRN_HIP(c, hipGetLastError());
   c->have_H = true;
+  c->H_shifted = false;
   c->have_L = false;
   return LRN_OK;
 }
@@ -471,6 +480,7 @@ int schur_add_diag(lrn_ctx* c, double eps) {
   hipLaunchKernelGGL(add_diag_kernel, dim3((c->nvar + 255) / 256), dim3(256), 0, c->stream, c->H.as<double>(),
                      c->nvar, eps);
   c->have_L = false;
+  if (eps != 0.0) c->H_shifted = true;
   return LRN_OK;
 }
 
@@ -494,20 +504,28 @@ int schur_factor(lrn_ctx* c, int* info) {
   LRN_TRY(ensure(c, c->cholwork, (size_t)n * CHOL_NB * 8));
   hipEvent_t a0, a1;
   if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
-  LRN_HIP(c, hipMemcpyAsync(c->L.p, c->H.p, bytes, hipMemcpyDeviceToDevice, c->stream));
-  LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 8, c->stream));
   // H is positive semidefinite by construction; late in a solve its smallest eigenvalues sink below the
   // rounding level of the assembly (tru9: lambda_min = -1e-3 at |H| = 4e12).  Pivots at that level are
-  // boosted instead of failing the factorisation -- the reference's +1e-4 I loop (:59-85) remains the
-  // fallback for anything worse (more than max(8, n/64) such pivots, NaNs).
+  // boosted instead of failing the factorisation.  If more than max(8, n/64) pivots are affected the
+  // attempt is abandoned and the strict factorisation decides -- this library never fails where a plain
+  // Cholesky succeeds --, and once the caller has entered the reference's +1e-4 I loop (:59-85,
+  // lrn_schur_add_diag) only the strict factorisation is used, as there.
   LRN_TRY(ensure(c, c->hdiag, (size_t)n * 8));
-  hipLaunchKernelGGL(get_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->H.as<double>(), n,
-                     c->hdiag.as<double>());
-  LRN_TRY(potrf_lower_boost(c->stream, c->L.as<double>(), n, n, c->Linv.as<double>(), c->cholwork.as<double>(),
-                            c->info_dev.as<int>(), opt_pivot_boost > 0.0 ? c->hdiag.as<double>() : nullptr,
-                            opt_pivot_boost, std::max(8, n / 64)));
   int h_two[2] = {0, 0};
-  LRN_HIP(c, hipMemcpyAsync(h_two, c->info_dev.p, 8, hipMemcpyDeviceToHost, c->stream));
+  const bool try_boost = opt_pivot_boost > 0.0 && !c->H_shifted;
+  for (int attempt = try_boost ? 0 : 1; attempt < 2; ++attempt) {
+    LRN_HIP(c, hipMemcpyAsync(c->L.p, c->H.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 8, c->stream));
+    if (attempt == 0)
+      hipLaunchKernelGGL(get_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->H.as<double>(), n,
+                         c->hdiag.as<double>());
+    LRN_TRY(potrf_lower_boost(c->stream, c->L.as<double>(), n, n, c->Linv.as<double>(), c->cholwork.as<double>(),
+                              c->info_dev.as<int>(), attempt == 0 ? c->hdiag.as<double>() : nullptr, opt_pivot_boost,
+                              std::max(8, n / 64)));
+    LRN_HIP(c, hipMemcpyAsync(h_two, c->info_dev.p, 8, hipMemcpyDeviceToHost, c->stream));
+    LRN_HIP(c, hipStreamSynchronize(c->stream));
+    if (h_two[0] == 0) break;
+  }
   if (c->profile) { (void)hipEventRecord(a1, c->stream); }
   LRN_HIP(c, hipStreamSynchronize(c->stream));
   if (c->profile) {

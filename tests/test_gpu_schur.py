@@ -241,3 +241,33 @@ def test_against_committed_golden_iterate(dev):
     assert relerr(h, g["h"]) < 1e-10
     assert dev.schur_factor() == 0
     assert relerr(dev.schur_solve(g["h"]), g["dely"]) < 1e-8
+
+
+def test_two_dense_blocks_second_larger(dev):
+    """Regression (found by tools/fuzz_parity.py): the MFMA-path workspaces were sized for the first LMI
+    block; a larger second block with dense constraints wrote past them."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(42)
+    nvar, sizes = 30, [17, 29]
+    A = []
+    for m in sizes:
+        blk = [sp.csc_matrix((m, m))]
+        for k in range(nvar):
+            R = rng.standard_normal((m, m)) * (rng.random((m, m)) < (1.0 if k % 3 else 0.3))
+            blk.append(sp.csc_matrix(R + R.T))
+        A.append(blk)
+    model = lo.make_model(A, np.ones(nvar), 0.0, None, None)
+    dev.set_option("dense_threshold", 50)         # every constraint with >= 50 entries takes the MFMA path
+    try:
+        dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    finally:
+        dev.set_option("dense_threshold", -1)
+    W = []
+    for i, m in enumerate(sizes):
+        w, g = _spd(m, 10 + i)
+        W.append(w)
+        dev.set_scaling(i, w, g)
+    H = dev.schur_assemble(0, want_H=True)
+    Href = lo.makeBBBBs(model.n, model.nlmi, model.A, model.AA, W, model.qA, model.sigmaA)
+    Href = np.tril(Href) + np.tril(Href, -1).T
+    assert relerr(H, Href) < 1e-13

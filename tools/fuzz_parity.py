@@ -8,15 +8,18 @@ from loraine_jl_amd.optimizer import Optimizer
 from oracle import loraine_oracle as lo
 
 def random_problem(rng):
-    nvar = int(rng.integers(3, 14))
-    nblk = int(rng.integers(1, 4))
-    sizes = [int(rng.integers(1, 9)) for _ in range(nblk)]
+    big = os.environ.get("FUZZ_BIG") is not None          # sizes where the PCG path is meaningful
+    nvar = int(rng.integers(20, 60)) if big else int(rng.integers(3, 14))
+    nblk = int(rng.integers(1, 3)) if big else int(rng.integers(1, 4))
+    sizes = [int(rng.integers(10, 30)) if big else int(rng.integers(1, 9)) for _ in range(nblk)]
     y0 = rng.standard_normal(nvar)
     A = []
-    for m in sizes:
+    for bi, m in enumerate(sizes):
         blk = [None]
         for k in range(nvar):
             kind = rng.integers(0, 4)
+            if big and kind == 0 and (bi == 0 or rng.random() < 0.8):
+                kind = 2          # FUZZ_BIG: every variable gets LMI entries (H nonsingular), few empty matrices
             if kind == 0:
                 M = np.zeros((m, m))                                   # empty constraint matrix
             elif kind == 1:
