@@ -7,17 +7,29 @@ import numpy as np, scipy.sparse as sp
 from loraine_jl_amd.optimizer import Optimizer
 from oracle import loraine_oracle as lo
 
+RANK1 = os.environ.get("FUZZ_RANK1") is not None
+
+
 def random_problem(rng):
     big = os.environ.get("FUZZ_BIG") is not None          # sizes where the PCG path is meaningful
     nvar = int(rng.integers(20, 60)) if big else int(rng.integers(3, 14))
     nblk = int(rng.integers(1, 3)) if big else int(rng.integers(1, 4))
     sizes = [int(rng.integers(10, 30)) if big else int(rng.integers(1, 9)) for _ in range(nblk)]
+    if os.environ.get("FUZZ_HUGE") is not None:          # blocks around the 128-wide tile boundary
+        nvar = int(rng.integers(15, 40))
+        sizes = [int(rng.integers(100, 160)) for _ in range(nblk)]
     y0 = rng.standard_normal(nvar)
     A = []
     for bi, m in enumerate(sizes):
         blk = [None]
         for k in range(nvar):
             kind = rng.integers(0, 4)
+            if RANK1:                                    # datarank = -1: A_k = v v' with a sparse v
+                v = rng.standard_normal(m) * (rng.random(m) < max(0.15, 2.0 / m))
+                if not v.any():
+                    v[rng.integers(0, m)] = 1.0
+                blk.append(sp.csc_matrix(np.outer(v, v)))
+                continue
             if big and kind == 0 and (bi == 0 or rng.random() < 0.8):
                 kind = 2          # FUZZ_BIG: every variable gets LMI entries (H nonsingular), few empty matrices
             if kind == 0:
@@ -54,14 +66,15 @@ def main():
     for s in range(seed0, seed0 + count):
         rng = np.random.default_rng(s)
         A, b, d_lin, C_lin = random_problem(rng)
-        kits = (dict(kit=0),) if os.environ.get("FUZZ_KIT1") is None else (
+        kits = (dict(kit=0, datarank=-1),) if RANK1 else (dict(kit=0),) if os.environ.get("FUZZ_KIT1") is None else (
             dict(kit=0), dict(kit=1, preconditioner=2, eDIMACS=1e-6), dict(kit=1, preconditioner=1, eDIMACS=1e-6))
         for opts in kits:
             if opts["kit"] == 1 and (opts["preconditioner"] == 1 and C_lin is not None and False):
                 continue
             try:
                 om = lo.make_model([[m.copy() for m in blk] for blk in A], b.copy(), 0.0,
-                                   None if d_lin is None else d_lin.copy(), None if C_lin is None else C_lin.copy())
+                                   None if d_lin is None else d_lin.copy(), None if C_lin is None else C_lin.copy(),
+                                   datarank=int(opts.get("datarank", 0)))
                 ref = lo.MySolver(om, dict(opts, verb=0)); lo.solve(ref)
                 rs, ro, ri = ref.status, lo.objective_value(ref), ref.iter
             except Exception as e:
