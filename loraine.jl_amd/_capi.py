@@ -127,6 +127,11 @@ def ptr(a):
     if isinstance(a, np.ndarray):
         return C.c_void_p(a.ctypes.data)
     if hasattr(a, "data_ptr"):
+        # the library works on its own HIP stream: whatever torch still has queued for this tensor (its
+        # zero-fill, an arithmetic result) must have landed before the pointer is handed over
+        if getattr(a, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream(a.device).synchronize()
         return C.c_void_p(a.data_ptr())
     raise TypeError(type(a))
 

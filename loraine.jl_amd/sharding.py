@@ -155,7 +155,8 @@ class ShardedCG:
         b = torch.as_tensor(np.asarray(h, float)).cuda()
 
         # the library works on its own HIP stream: torch's stream must have finished writing a tensor
-        # before its pointer is handed over (the library's calls are blocking, so the way back is safe)
+        # before its pointer is handed over (_capi.ptr() synchronises as well; the library's calls are
+        # blocking, so the way back is safe)
         def mv(p):
             out = torch.empty_like(p)
             torch.cuda.current_stream().synchronize()

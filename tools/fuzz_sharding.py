@@ -52,6 +52,10 @@ for s in range(seed0, seed0 + count):
     dev.set_shard(0, 1); dev.set_option("shard_bs", 0)
     if not np.array_equal(np.tril(H2), np.tril(Hf)):
         bad += 1
+        Hg = dev.schur_assemble(0, want_H=True)          # unsharded general path as the referee
+        ng = max(np.linalg.norm(np.tril(Hg)), 1e-300)
+        print(f"   unsharded vs general {np.linalg.norm(np.tril(Hf - Hg)) / ng:.2e}; sharded vs general {np.linalg.norm(np.tril(H2 - Hg)) / ng:.2e}; "
+              f"differing entries {int((np.tril(H2) != np.tril(Hf)).sum())}, first {np.argwhere(np.tril(H2) != np.tril(Hf))[:3].tolist()}")
         print(f"MISMATCH seed {s}: m={m} nvar={nvar} rank1={rank1} nlin={nlin} world={world} bs={bs} "
               f"rel err {np.linalg.norm(np.tril(H2 - Hf)) / max(np.linalg.norm(np.tril(Hf)), 1e-300):.2e}", flush=True)
     if (s - seed0) % 10 == 9: print(f"... {s - seed0 + 1} models, {bad} mismatches", flush=True)
