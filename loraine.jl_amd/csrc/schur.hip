@@ -274,8 +274,11 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   }
   const long P_cap = b.p_cap, T_cap = b.t_cap;
   LRN_TRY(ensure(c, c->P, (size_t)P_cap * mm * 8));
-  LRN_TRY(ensure(c, c->T, (size_t)T_cap * mm * 8, true));   // upper tiles stay zero between assemblies ...
-  if (c->T_m != m || c->T_owner != &b) {                    // ... of the SAME block: another layout left its data
+  const void* t_before = c->T.p;
+  LRN_TRY(ensure(c, c->T, (size_t)T_cap * mm * 8));         // (a fresh allocation comes back zeroed)
+  if (c->T.p != t_before) { c->T_m = m; c->T_owner = &b; }
+  // upper tiles stay zero between assemblies of the SAME block; another block's layout left its data
+  if (c->T_m != m || c->T_owner != &b) {
     LRN_HIP(c, hipMemsetAsync(c->T.p, 0, (size_t)T_cap * mm * 8, c->stream));
     c->T_m = m;
     c->T_owner = &b;
