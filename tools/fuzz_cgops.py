@@ -15,6 +15,7 @@ def spd(rng, m, cond):
     M = (Q * lam) @ Q.T
     return 0.5 * (M + M.T)
 
+SPARSE_MV = os.environ.get("FUZZ_SPARSE_MV") is not None    # all-sparse models, pattern-restricted mat-vec forced
 dev = loraine_jl_amd.Device(0)
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -27,7 +28,7 @@ for s in range(seed0, seed0 + count):
     for m in sizes:
         blk = [sp.csc_matrix((m, m))]
         for k in range(nvar):
-            kind = rng.integers(0, 5)
+            kind = rng.integers(0, 4 if SPARSE_MV else 5)
             if kind == 0 and len(A) > 0: M = np.zeros((m, m))
             elif kind <= 1:
                 M = np.zeros((m, m)); i, j = rng.integers(0, m, 2); M[i, j] += 1.3; M[j, i] += 1.3
@@ -59,8 +60,18 @@ for s in range(seed0, seed0 + count):
     x = rng.standard_normal(nvar)
     Ao = lo.MyA(so.W, om.AA, om.nlin, om.C_lin, so.X_lin, so.S_lin_inv)
     ref = np.zeros(nvar); Ao(ref, x)
+    if SPARSE_MV: dev.set_option("matvec_sparse", 2)
     e = relerr(dev.matvec(x), ref)
     if e > 1e-11: msgs.append(f"matvec {e:.1e}")
+    if SPARSE_MV:
+        from loraine_jl_amd._capi import ptr
+        acc = np.zeros(nvar)
+        for r in range(3):
+            dev.set_shard(r, 3); part = np.zeros(nvar)
+            dev._chk(dev.lib.lrn_matvec_partial(dev.h, ptr(x), ptr(part)), "lrn_matvec_partial"); acc += part
+        dev.set_shard(0, 1); dev.set_option("matvec_sparse", 0)
+        e = relerr(acc, ref)
+        if e > 1e-11: msgs.append(f"partial mat-vec sum {e:.1e}")
     for prec in (2, 1):
         for eig in (1, 2):
             ha = lo.Halpha(1); so.preconditioner, so.erank = prec, erank
