@@ -86,6 +86,8 @@ struct lrn_ctx {
   lrn::DBuf m0, m1, m2, cgbuf;   // msz^2 work matrices (mat-vec / rhs), PCG vectors
   int T_m = 0;                 // matrix side and block the T workspace was last laid out for
   const void* T_owner = nullptr;
+  int T_layout = 0;            // 0: msz^2 per matrix, lower tiles (T_k = W A_k W); 1: packed lower tiles (L' A_k L)
+  lrn::DBuf wchol;             // Cholesky path of the assembly: factor of W, its transpose, work
   // shard (multi-GPU): this rank assembles owner columns with (pos / shard_bs) % world == rank
   int rank = 0, world = 1, shard_bs = 128;
   int shard_bs_opt = 0;         // option "shard_bs": 0 = auto (see update_shard_bs)

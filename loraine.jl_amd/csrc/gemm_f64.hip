@@ -84,6 +84,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     kcur = (long)ks * p.kchunk;
     kend = kcur + p.kchunk;
     if (kend > d.K) kend = d.K;
+    if (d.flags & GEMM_KFROM_N) kcur = n0;          // (ksplit == 1: checked by the launcher)
+    if (d.flags & GEMM_KFROM_M) kcur = m0;
   }
 
   // ---- per-thread staging geometry
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   // number of chunks is uniform across the workgroup (depends only on block indices)
   {
     // first chunk may not exist at all (empty split): then nothing to do
-    bool any = KSEG ? (p.kcols[ks] < p.kcols[ks + 1]) : ((long)ks * p.kchunk < d.K);
+    bool any = KSEG ? (p.kcols[ks] < p.kcols[ks + 1])
+                    : ((d.flags & (GEMM_KFROM_N | GEMM_KFROM_M)) ? true : ((long)ks * p.kchunk < d.K));
     more = any;
   }
   while (more) {
@@ -191,6 +194,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
   const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
   const bool sq = EPI && (d.flags & GEMM_SQUARE);
+  // packed lower-tile C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
+  const bool pk = EPI && (d.flags & GEMM_C_PACKED);
+  const int pkS = packed_S(d.pk_m);
+  const long pkKd = packed_diag_elems(d.pk_m > 0 ? d.pk_m : 1);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
         if (m < d.M && n < d.N) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
-          double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
+          double* c = pk ? Cg + packed_lower_offset(n, m, pkS, pkKd) : Cg + (long)m * d.sCm + (long)n * d.sCn;
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
         }
@@ -238,6 +245,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     int bid = blockIdx.x, nwg = gridDim.x;
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // triangular-K products: the tiles of one matrix differ in K length, and with nwg % 8 == 0 every
+    // XCD would get the same run of the list for every batch element -- rotate the runs over the XCDs
+    if ((d.flags & (GEMM_KFROM_N | GEMM_KFROM_M)) && r == 0) {
+      xcd = (xcd + (int)blockIdx.z) & 7;
+      swz = xcd * q + (bid >> 3);
+    }
     int2 tt = p.tile_list[swz];
     tm = tt.x;
     tn = tt.y;
@@ -287,9 +300,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   };
 
   const int fr = lane & 15, fk = lane >> 4;
-  issue(0, 0);
+  // K loop from the tile origin when an operand is triangular (tile origins are multiples of 128)
+  const int kt0 = (d.flags & GEMM_KFROM_N) ? n0 / BK : ((d.flags & GEMM_KFROM_M) ? m0 / BK : 0);
+  issue(kt0, kt0 & 1);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
     const double* sa = lds + cur * (2 * LA);
@@ -313,6 +328,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
   const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
   const bool sq = EPI && (d.flags & GEMM_SQUARE);
+  // packed lower-tile C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
+  const bool pk = EPI && (d.flags & GEMM_C_PACKED);
+  const int pkS = packed_S(d.pk_m);
+  const long pkKd = packed_diag_elems(d.pk_m > 0 ? d.pk_m : 1);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
         if (m < d.M && n < d.N) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
-          double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
+          double* c = pk ? Cg + packed_lower_offset(n, m, pkS, pkKd) : Cg + (long)m * d.sCm + (long)n * d.sCn;
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
         }
@@ -339,7 +358,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
 // of the fragment reads are removed by an XOR swizzle of the 16-byte k-pair index with
 // (row>>1)&7, applied to the SOURCE address and to the read (both-sides rule).  Rows beyond
 // M/N are clamped to the last valid row (their results are never stored).
-template <bool EPI_UNUSED>
+// FLAT (GEMM_KFLAT): K is the flat index of the packed lower-tile layout, walked in chunks of 16;
+// kcols[] then holds chunk indices.
+template <bool FLAT>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
   constexpr int LA = BM * BK;                   // doubles per image (unpadded)
@@ -378,8 +399,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
     pb[j] = Bg + (long)rb * d.sBn + 2 * src_pair;
   }
   int segc = p.kcols[ks], segcend = p.kcols[ks + 1];
-  int segr = (segc / 128) * 128;
+  int segr = FLAT ? 0 : (segc / 128) * 128;
   const int ld = d.kseg_ld;
+  auto chunk_base = [&]() -> long { return FLAT ? (long)segc * BK : (long)segc * ld + segr; };
 
   v4f64 acc[TM][TN];
 #pragma unroll
@@ -400,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
     }
   };
   auto next_chunk = [&]() {
+    if (FLAT) { ++segc; return; }
     segr += BK;
     if (segr >= ld) { ++segc; segr = (segc / 128) * 128; }
   };
@@ -407,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   const int fr = lane & 15, fk = lane >> 4;
   bool more = segc < segcend;
   if (more) {
-    issue((long)segc * ld + segr, 0);
+    issue(chunk_base(), 0);
     next_chunk();
   }
   __syncthreads();
@@ -415,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   while (more) {
     const bool have_next = segc < segcend;
     if (have_next) {
-      issue((long)segc * ld + segr, cur ^ 1);
+      issue(chunk_base(), cur ^ 1);
       next_chunk();
     }
     const double* sa = lds + cur * (2 * LA);
@@ -458,7 +481,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
 
 static bool kseg_lds_path_ok(const GemmDesc& d) {
   if (d.sAk != 1 || d.sBk != 1 || d.beta != 0.0) return false;
-  if ((d.kseg_ld & 15) || (d.sAm & 1) || (d.sBn & 1) || (d.bA & 1) || (d.bB & 1)) return false;
+  if ((d.flags & GEMM_KFLAT) ? ((d.kflat_total & 15) || (d.kflat_diag & 15)) : (d.kseg_ld & 15)) return false;
+  if ((d.sAm & 1) || (d.sBn & 1) || (d.bA & 1) || (d.bB & 1)) return false;
   if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15)) return false;
   if (d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE)) return false;
   return true;
@@ -517,7 +541,11 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   // Orient so that the kernel's n (lane-contiguous in the MFMA result) is the contiguous
   // dimension of C: C^T = B^T A^T.
   long asCm = d.sCm < 0 ? -d.sCm : d.sCm, asCn = d.sCn < 0 ? -d.sCn : d.sCn;
+  bool swapped = false;
   if (asCm < asCn) {
+    swapped = true;
+    if (d.flags & GEMM_KFROM_N) d.flags = (d.flags & ~GEMM_KFROM_N) | GEMM_KFROM_M;
+    else if (d.flags & GEMM_KFROM_M) d.flags = (d.flags & ~GEMM_KFROM_M) | GEMM_KFROM_N;
     std::swap(d.A, d.B);
     std::swap(d.bA, d.bB);
     long sAm = d.sBn, sAk = d.sBk, sBk = d.sAk, sBn = d.sAm;
@@ -528,14 +556,32 @@ int gemm(hipStream_t st, const GemmDesc& din) {
     else if (d.flags & GEMM_TRI_UPPER) d.flags = (d.flags & ~GEMM_TRI_UPPER) | GEMM_TRI_LOWER;
   }
   const bool tri = d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER);
-  const bool kseg = d.flags & GEMM_KSEG_TRI;
+  const bool kflat = d.flags & GEMM_KFLAT;
+  const bool kseg = (d.flags & GEMM_KSEG_TRI) || kflat;
+  const bool kfrom = d.flags & (GEMM_KFROM_N | GEMM_KFROM_M);
+  if (kfrom && (d.ksplit != 1 || d.M != d.N || d.M != d.K || kseg)) return LRN_ERR_ARG;
+  if ((d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)) return LRN_ERR_ARG;
   // tile choice: 128x128 unless the problem is too small to fill the chip with it
   long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit;
-  bool small = (d.flags & GEMM_SMALL_TILE) || (t128 < 256 && !(d.flags & GEMM_OFFDIAG_X2) && !kseg);
+  bool small = (d.flags & GEMM_SMALL_TILE) ||
+               (t128 < 256 && !(d.flags & (GEMM_OFFDIAG_X2 | GEMM_C_PACKED)) && !kseg && !kfrom);
   const int BMv = small ? 64 : 128;
   p.tilesM = (d.M + BMv - 1) / BMv;
   p.tilesN = (d.N + BMv - 1) / BMv;
-  if (kseg) {
+  if (kflat) {
+    // chunk (16 doubles) boundaries per split: kflat_nsd splits over the diagonal region, the rest over
+    // the strictly-lower region (the caller weights their slabs by 2)
+    if (d.kflat_total <= 0 || d.kflat_diag <= 0 || d.kflat_diag > d.kflat_total || d.kflat_nsd < 1 ||
+        d.kflat_nsd > d.ksplit || !kseg_lds_path_ok(d))
+      return LRN_ERR_ARG;
+    if ((d.kflat_nsd == d.ksplit) != (d.kflat_diag == d.kflat_total)) return LRN_ERR_ARG;
+    d.K = (int)(d.kflat_total > 0x7fffffff ? 0x7fffffff : d.kflat_total);
+    const long cd = d.kflat_diag / BK, ct = d.kflat_total / BK;
+    const int nsd = d.kflat_nsd, nso = d.ksplit - nsd;
+    for (int s = 0; s <= nsd; ++s) p.kcols[s] = (int)(cd * s / nsd);
+    for (int s = 1; s <= nso; ++s) p.kcols[nsd + s] = (int)(cd + (ct - cd) * s / nso);
+    p.kchunk = 0;
+  } else if (kseg) {
     if (d.kseg_ld <= 0 || d.kseg_cols <= 0) return LRN_ERR_ARG;
     d.K = d.kseg_ld * d.kseg_cols;
     // balance splits by segment length sum
@@ -564,7 +610,11 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   const bool bkc = (d.sBk == 1 && d.sBn != 1);
   dim3 grid(ntile, 1, d.batch * d.ksplit);
   if (grid.z > 65535) return LRN_ERR_ARG;
-  const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE);
+  const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE | GEMM_C_PACKED);
+  if (kflat) {
+    hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true>), grid, dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
   if (kseg && kseg_lds_path_ok(d)) {
     hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<false>), grid, dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;

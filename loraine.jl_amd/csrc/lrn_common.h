@@ -49,7 +49,42 @@ enum : int {
                            // r < (c / 128) * 128 are skipped (upper tiles of a lower-stored
                            // symmetric operand)
   GEMM_SMALL_TILE = 32,    // force the 64x64 tile
+  GEMM_KFROM_N = 64,       // the K loop starts at the first column of the n-tile: op(B)[k][n] = 0 for
+                           // k < n (B is the transposed lower Cholesky factor); forces the 128 tile
+  GEMM_KFROM_M = 128,      // same with the m-tile (op(A)[m][k] = 0 for k < m)
+  GEMM_C_PACKED = 256,     // C is an msz x msz symmetric matrix stored as packed lower 128-tiles
+                           // (packed_lower_offset below; pk_m, pk_S); needs sCm == 1 on entry
+  GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower-tile layout;
+                           // the first kflat_nsd splits cover the diagonal tiles [0, kflat_diag), the
+                           // others the strictly-lower tiles [kflat_diag, K)
 };
+
+// ---------------------------------------------------------------- packed lower-tile layout
+// A symmetric msz x msz matrix of which only the 128-tiles on and below the diagonal are kept
+// (schur.hip, Cholesky path: At_k = L' A_k L).  S = msz rounded up to 16.  Flat index space:
+//   [0, Kd)   diagonal tiles, tile t at t*128*128, column-major with column length min(128, S-128t)
+//   [Kd, Kp)  per column c (tile t): rows 128(t+1) .. S-1, contiguous
+// Every column piece is a multiple of 16 doubles, rows >= msz are never written (stay zero), so a
+// K walk in chunks of 16 never straddles the two regions.  <X,Y> = sum over [0,Kd) + 2 * sum over [Kd,Kp).
+__host__ __device__ inline int packed_S(int m) { return (m + 15) & ~15; }
+__host__ __device__ inline long packed_diag_elems(int m) {
+  const int nt = (m + 127) >> 7, S = packed_S(m);
+  const int sl = S - 128 * (nt - 1) < 128 ? S - 128 * (nt - 1) : 128;
+  return (long)(nt - 1) * 16384 + (long)(m - 128 * (nt - 1)) * sl;
+}
+__host__ __device__ inline long packed_off_base(int t, int S) { return 128L * ((long)t * S - 64L * t * (t + 1)); }
+__host__ __device__ inline long packed_total_elems(int m) {
+  return packed_diag_elems(m) + packed_off_base(((m + 127) >> 7) - 1, packed_S(m));
+}
+// offset of element (r, c), r / 128 >= c / 128
+__host__ __device__ inline long packed_lower_offset(int r, int c, int S, long Kd) {
+  const int t = c >> 7, cl = c & 127;
+  if ((r >> 7) == t) {
+    const int sl = S - 128 * t < 128 ? S - 128 * t : 128;
+    return (long)t * 16384 + (long)cl * sl + (r - 128 * t);
+  }
+  return Kd + packed_off_base(t, S) + (long)cl * (S - 128 * (t + 1)) + (r - 128 * (t + 1));
+}
 
 struct GemmDesc {
   const double* A = nullptr;
@@ -67,6 +102,10 @@ struct GemmDesc {
   long sCs = 0;
   // GEMM_KSEG_TRI: K = kseg_ld * kseg_cols, segment list derived from (ld, cols)
   int kseg_ld = 0, kseg_cols = 0;
+  // GEMM_C_PACKED: side of the packed matrix.  GEMM_KFLAT: K = kflat_total, diagonal region and its splits
+  int pk_m = 0;
+  long kflat_total = 0, kflat_diag = 0;
+  int kflat_nsd = 0;
 };
 
 int gemm(hipStream_t st, const GemmDesc& d);

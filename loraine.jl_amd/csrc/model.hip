@@ -170,10 +170,11 @@ void lrn_free_model(lrn_ctx* c) {
   c->lmi.clear();
   for (DBuf* d : {&c->cl_ptr, &c->cl_row, &c->cl_val, &c->lin_xs, &c->H, &c->L, &c->Linv, &c->cholwork,
                   &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->T, &c->slabs, &c->Hd, &c->BG, &c->m0, &c->m1, &c->m2, &c->cgbuf, &c->cl_rown,
-                  &c->hdiag, &c->lp_r, &c->lp_c, &c->lp_ptr, &c->lp_l, &c->lp_w, &c->cr_ptr, &c->cr_col, &c->cr_val})
+                  &c->hdiag, &c->wchol, &c->lp_r, &c->lp_c, &c->lp_ptr, &c->lp_l, &c->lp_w, &c->cr_ptr, &c->cr_col, &c->cr_val})
     release(*d);
   c->T_m = 0;
   c->T_owner = nullptr;
+  c->T_layout = 0;
   c->have_H = c->have_L = false;
   c->nlmi = c->nvar = c->nlin = 0;
 }

@@ -27,6 +27,7 @@
 namespace lrn {
 
 static constexpr int TS = 128;   // packing tile of the lower-stored T
+static constexpr int BK_CHUNK = 16;   // K chunk of the GEMM kernels
 
 // ------------------------------------------------------------------ sparse pair kernels
 __device__ __forceinline__ double wave_sum(double v) {
@@ -118,15 +119,34 @@ __global__ __launch_bounds__(256) void dense_sparse_gather_kernel(
 }
 
 // out[(r0+i) + (c0+j)*ldo] += sum_s slab_s[i + j*M]   for computed (lower) tiles
-__global__ void reduce_slabs_tri_kernel(const double* __restrict__ slabs, long stride, int nslab, int M,
+// slabs [nw1, nslab) count twice (strictly-lower tiles of the packed symmetric operands, Cholesky path)
+__global__ void reduce_slabs_tri_kernel(const double* __restrict__ slabs, long stride, int nslab, int nw1, int M,
                                         int N, double* __restrict__ out, long ldo) {
   long total = (long)M * N;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     int i = (int)(e % M), j = (int)(e / M);
     if (i / TS < j / TS) continue;
-    double s = 0.0;
-    for (int k = 0; k < nslab; ++k) s += slabs[(long)k * stride + e];
-    out[(long)i + (long)j * ldo] += s;
+    double s = 0.0, s2 = 0.0;
+    for (int k = 0; k < nw1; ++k) s += slabs[(long)k * stride + e];
+    for (int k = nw1; k < nslab; ++k) s2 += slabs[(long)k * stride + e];
+    out[(long)i + (long)j * ldo] += s + 2.0 * s2;
+  }
+}
+
+// Ut[n + k*m] = L[k + n*m] for k >= n, else 0: the transposed lower Cholesky factor with explicit zeros
+__global__ __launch_bounds__(256) void transpose_lower_kernel(const double* __restrict__ L, int m,
+                                                              double* __restrict__ Ut) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;      // bx: rows k of L, by: columns n of L
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    int k = bx + tx, n = by + j;
+    tile[j][tx] = (k < m && n < m && k >= n) ? L[(long)k + (long)n * m] : 0.0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int n = by + tx, k = bx + j;
+    if (n < m && k < m) Ut[(long)n + (long)k * m] = tile[tx][j];
   }
 }
 
@@ -250,7 +270,157 @@ static long pick_p_batch(int m, long limit) {
   return best;
 }
 
+// ---- Cholesky path of the dense assembly.  With W = L L' (L lower triangular)
+//        H_ij = tr(A_i W A_j W) = < L' A_i L , L' A_j L >,
+// so the triangular factor replaces the two full products per constraint (3 msz^3 flop) by
+//        GEMM1'  P_k  = A_k L,  lower tiles only, K from the tile's column origin   (2/3 msz^3)
+//        GEMM2'  At_k = L' P_k, lower tiles only, K from the tile's row origin      (1/3 msz^3)
+// and the inner products become a symmetric rank-k update over the packed lower tiles of all At_k
+//        GEMM3'  H[j,i] = <At_j, At_i>   (nvar^2 msz^2 / 2, as before).
+// The perturbation is that of a backward-stable Cholesky of W (||L L' - W|| <= c msz eps ||W||), the level W
+// itself is known to; when the factorisation of W breaks down (W numerically singular late in a solve) the
+// T_k = W A_k W path below takes over.  Every rank needs every At_k, so with the column sharding the products
+// are replicated: the path is chosen for world <= 2 only (1.1 msz^3 * nd  vs  3 msz^3 * nd / world).
+int opt_schur_chol = -1;     // option "schur_chol": -1 auto, 0 never, 1 whenever the data allows it
+
+static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
+  if (opt_schur_chol == 0) return false;
+  if (b.npos_nz != b.nd || b.nd < 2 || b.msz < 2) return false;   // sparse partners gather from T_k = W A_k W itself
+  if (opt_schur_chol < 0 && (1.1 * c->world >= 3.0 || b.msz < 256)) return false;
+  const long mm = (long)b.msz * b.msz;
+  long pcap = opt_p_batch > 0 ? opt_p_batch : 64;
+  if (pcap > b.nd) pcap = b.nd;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes) * 0.92;
+  double need = (double)b.nd * packed_total_elems(b.msz) * 8.0 + (double)pcap * mm * 8.0 + 1.0e9;
+  if (need > avail) return false;
+  *pcap_out = pcap;
+  return true;
+}
+
+// returns LRN_OK with *done = false when W could not be factored (caller falls back)
+static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap, bool* done) {
+  const int m = b.msz, nd = b.nd, n = c->nvar;
+  const long mm = (long)m * m;
+  const long Kp = packed_total_elems(m), Kd = packed_diag_elems(m);
+  *done = false;
+  // ---- W = L L'
+  const size_t linv = chol_linv_doubles(m);
+  LRN_TRY(ensure(c, c->wchol, (2 * (size_t)mm + linv + (size_t)m * CHOL_NB) * 8));
+  double* Lw = c->wchol.as<double>();
+  double* Ut = Lw + mm;
+  double* Linv = Ut + mm;
+  double* cw = Linv + linv;
+  tic(c);
+  LRN_HIP(c, hipMemcpyAsync(Lw, b.W.p, (size_t)mm * 8, hipMemcpyDeviceToDevice, c->stream));
+  LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 8, c->stream));
+  LRN_TRY(potrf_lower(c->stream, Lw, m, m, Linv, cw, c->info_dev.as<int>()));
+  int h_info = 0;
+  LRN_HIP(c, hipMemcpyAsync(&h_info, c->info_dev.p, 4, hipMemcpyDeviceToHost, c->stream));
+  LRN_HIP(c, hipStreamSynchronize(c->stream));
+  if (h_info != 0) {
+    c->counts["wchol_fail"] += 1;
+    return LRN_OK;
+  }
+  hipLaunchKernelGGL(transpose_lower_kernel, dim3((m + 31) / 32, (m + 31) / 32), dim3(256), 0, c->stream, Lw, m, Ut);
+  toc(c, "wchol");
+  // ---- workspaces: P (batch of row-major A_k L), T (all At_k, packed)
+  LRN_TRY(ensure(c, c->P, (size_t)P_cap * mm * 8));
+  const void* t_before = c->T.p;
+  LRN_TRY(ensure(c, c->T, (size_t)nd * Kp * 8));            // (a fresh allocation comes back zeroed)
+  if (c->T.p == t_before && (c->T_layout != 1 || c->T_m != m || c->T_owner != &b))
+    LRN_HIP(c, hipMemsetAsync(c->T.p, 0, (size_t)nd * Kp * 8, c->stream));   // padding rows must be zero
+  c->T_layout = 1;
+  c->T_m = m;
+  c->T_owner = &b;
+  double* Ad = b.Adense.as<double>();
+  double* P = c->P.as<double>();
+  double* T = c->T.as<double>();
+  for (int a = 0; a < nd; a += (int)P_cap) {
+    int nb = std::min((int)P_cap, nd - a);
+    tic(c);
+    GemmDesc g1;   // P = A_a L, row-major (P[i][j] at j + i*m), tiles i >= j, K from the tile's column origin
+    g1.A = Ad + (long)a * mm; g1.sAm = 1; g1.sAk = m; g1.bA = mm;
+    g1.B = Ut; g1.sBk = m; g1.sBn = 1; g1.bB = 0;           // op(B)[k][j] = L[k,j] = Ut[j + k*m]
+    g1.C = P; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
+    g1.M = g1.N = g1.K = m; g1.batch = nb;
+    g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N;
+    LRN_TRY(gemm(c->stream, g1));
+    toc(c, "gemm1");
+    tic(c);
+    GemmDesc g2;   // At = L' P, tiles i >= j, K from the tile's row origin, stored packed
+    g2.A = Ut; g2.sAm = 1; g2.sAk = m; g2.bA = 0;           // op(A)[i][k] = L[k,i] = Ut[i + k*m]
+    g2.B = P; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
+    g2.C = T + (long)a * Kp; g2.sCm = 1; g2.sCn = m; g2.bC = Kp;
+    g2.M = g2.N = g2.K = m; g2.batch = nb;
+    g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED;
+    g2.pk_m = m;
+    LRN_TRY(gemm(c->stream, g2));
+    toc(c, "gemm2");
+  }
+  // ---- GEMM3': H[s0:nd, s0:s1] += At[s0:nd] . At[s0:s1]'  per owned column block
+  double* H = c->H.as<double>();
+  double* Hd = H;
+  long ldh = n;
+  if (!c->pos_space) {
+    LRN_TRY(ensure(c, c->Hd, (size_t)nd * nd * 8, true));
+    LRN_HIP(c, hipMemsetAsync(c->Hd.p, 0, (size_t)nd * nd * 8, c->stream));
+    Hd = c->Hd.as<double>();
+    ldh = nd;
+  }
+  std::vector<std::pair<int, int>> groups;
+  if (c->world > 1) {
+    for (int s0 = 0; s0 < nd; s0 += c->shard_bs)
+      if (shard_owner(s0 / c->shard_bs, c->world) == c->rank) groups.push_back({s0, std::min(nd, s0 + c->shard_bs)});
+  } else {
+    groups.push_back({0, nd});
+  }
+  for (auto& g : groups) {
+    const int s0 = g.first, s1 = g.second;
+    tic(c);
+    const int M = nd - s0, N = s1 - s0;
+    long tiles = 0;
+    int tM = (M + TS - 1) / TS, tN = (N + TS - 1) / TS;
+    for (int tn = 0; tn < tN; ++tn) tiles += std::max(0, tM - tn);
+    int ksplit = pick_ksplit(tiles, (int)std::min<long>(64, std::max<long>(1, Kp / BK_CHUNK / 8)));
+    int nsd = ksplit;
+    if (Kd < Kp) {
+      if (ksplit < 2) ksplit = 2;
+      nsd = (int)((double)ksplit * (double)Kd / (double)Kp + 0.5);
+      nsd = std::max(1, std::min(ksplit - 1, nsd));
+    }
+    LRN_TRY(ensure(c, c->slabs, (size_t)ksplit * M * N * 8));
+    GemmDesc g3;
+    g3.A = T + (long)s0 * Kp; g3.sAm = Kp; g3.sAk = 1;
+    g3.B = T + (long)s0 * Kp; g3.sBk = 1; g3.sBn = Kp;
+    g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
+    g3.M = M; g3.N = N;
+    g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT;
+    g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = nsd;
+    g3.ksplit = ksplit; g3.sCs = (long)M * N;
+    LRN_TRY(gemm(c->stream, g3));
+    hipLaunchKernelGGL(reduce_slabs_tri_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,
+                       c->slabs.as<double>(), (long)M * N, ksplit, nsd, M, N, Hd + (long)s0 + (long)s0 * ldh, ldh);
+    toc(c, "gemm3");
+  }
+  if (!c->pos_space)
+    hipLaunchKernelGGL(scatter_add_lower_kernel, dim3(nblocks((long)nd * nd)), dim3(256), 0, c->stream, Hd, nd,
+                       b.hidx.as<int>(), H, n);
+  c->counts["schur_chol"] += 1;
+  *done = true;
+  return LRN_OK;
+}
+
 static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
+  {
+    long pcap = 0;
+    if (chol_path_applicable(c, b, &pcap)) {
+      bool done = false;
+      LRN_TRY(assemble_dense_chol(c, b, pcap, &done));
+      if (done) return LRN_OK;
+    }
+  }
   const int m = b.msz, nd = b.nd, n = c->nvar;
   const long mm = (long)m * m;
   double* W = b.W.as<double>();
@@ -278,11 +448,12 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   LRN_TRY(ensure(c, c->T, (size_t)T_cap * mm * 8));         // (a fresh allocation comes back zeroed)
   if (c->T.p != t_before) { c->T_m = m; c->T_owner = &b; }
   // upper tiles stay zero between assemblies of the SAME block; another block's layout left its data
-  if (c->T_m != m || c->T_owner != &b) {
+  if (c->T_m != m || c->T_owner != &b || c->T_layout != 0) {
     LRN_HIP(c, hipMemsetAsync(c->T.p, 0, (size_t)T_cap * mm * 8, c->stream));
     c->T_m = m;
     c->T_owner = &b;
   }
+  c->T_layout = 0;
   double* P = c->P.as<double>();
   double* T = c->T.as<double>();
   double* Hd = H;
@@ -349,7 +520,7 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
       g3.ksplit = ksplit; g3.sCs = (long)M * N;
       LRN_TRY(gemm(c->stream, g3));
       hipLaunchKernelGGL(reduce_slabs_tri_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,
-                         c->slabs.as<double>(), (long)M * N, ksplit, M, N, Hd + (long)s0 + (long)s0 * ldh, ldh);
+                         c->slabs.as<double>(), (long)M * N, ksplit, ksplit, M, N, Hd + (long)s0 + (long)s0 * ldh, ldh);
       toc(c, "gemm3");
     }
     // dense owner x sparse other

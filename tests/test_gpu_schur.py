@@ -98,18 +98,24 @@ def _dense_model(msz, nvar, seed, density=1.0):
     return lo.make_model(A, rng.standard_normal(nvar), 0.0, None, None)
 
 
-@pytest.mark.parametrize("msz,nvar", [(96, 40), (300, 130), (257, 300)])
-def test_dense_mfma_path_matches_oracle(dev, msz, nvar):
-    """The C4-shaped path: every constraint dense -> GEMM1/GEMM2/GEMM3."""
+@pytest.mark.parametrize("chol", [0, 1])
+@pytest.mark.parametrize("msz,nvar", [(96, 40), (300, 130), (257, 300), (16, 5), (130, 20), (333, 37)])
+def test_dense_mfma_path_matches_oracle(dev, msz, nvar, chol):
+    """The C4-shaped path: every constraint dense -> GEMM1/GEMM2/GEMM3; chol=0: T_k = W A_k W,
+    chol=1: the Cholesky path (L' A_k L on triangular K ranges, packed lower tiles, weighted slabs)."""
     model = _dense_model(msz, nvar, msz + nvar)
     W, G = _spd(msz, 5)
     dev.set_option("dense_threshold", 1)             # force the MFMA path regardless of the cost model
+    dev.set_option("schur_chol", chol)
     try:
         _upload(dev, model)
         dev.set_scaling(0, W, G)
+        dev.reset_timing()
         H = dev.schur_assemble(0, want_H=True)
+        assert dev.count("schur_chol") == chol
     finally:
         dev.set_option("dense_threshold", -1)
+        dev.set_option("schur_chol", -1)
     Amat = np.stack([model.A[0][k + 1].toarray() for k in range(nvar)])
     Href = _brute_H(Amat, W)
     assert relerr(H, Href) < 1e-13
@@ -271,3 +277,110 @@ def test_two_dense_blocks_second_larger(dev):
     Href = lo.makeBBBBs(model.n, model.nlmi, model.A, model.AA, W, model.qA, model.sigmaA)
     Href = np.tril(Href) + np.tril(Href, -1).T
     assert relerr(H, Href) < 1e-13
+
+
+def test_chol_path_equals_w_path_midsize(dev):
+    """Cholesky path vs the T_k = W A_k W path on a problem large enough for the direct-to-LDS kernels
+    (msz 1000: 8 tiles a side, K ranges 1000 ... 104), W with condition 1e6, auto selection."""
+    msz, nvar = 1000, 200
+    dev.synthetic_dense_model(msz, nvar, 7)
+    W, G = _spd(msz, 8, cond=1e6)
+    dev.set_scaling(0, W, G)
+    dev.reset_timing()
+    H1 = dev.schur_assemble(0, want_H=True)
+    assert dev.count("schur_chol") == 1              # auto: all constraints dense, one rank
+    dev.set_option("schur_chol", 0)
+    try:
+        dev.reset_timing()
+        H0 = dev.schur_assemble(0, want_H=True)
+        assert dev.count("schur_chol") == 0
+    finally:
+        dev.set_option("schur_chol", -1)
+    assert relerr(H1, H0) < 1e-13
+    assert np.array_equal(H1, H1.T)
+    A = np.stack([dev.get_constraint(0, k) for k in range(0, nvar, 50)])
+    Href = _brute_H(A, W)
+    assert relerr(H1[::50, ::50], Href) < 1e-13
+
+
+def test_chol_path_falls_back_when_w_is_singular(dev):
+    msz, nvar = 150, 12
+    model = _dense_model(msz, nvar, 77)
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((msz, msz - 20))         # 20 eigenvalues at -1e-6: the Cholesky of W breaks down
+    W = G @ G.T - 1e-6 * np.eye(msz)
+    dev.set_option("dense_threshold", 1)
+    dev.set_option("schur_chol", 1)
+    try:
+        _upload(dev, model)
+        dev.set_scaling(0, W, np.zeros((msz, msz)))
+        dev.reset_timing()
+        H = dev.schur_assemble(0, want_H=True)
+        assert dev.count("wchol_fail") == 1 and dev.count("schur_chol") == 0
+    finally:
+        dev.set_option("dense_threshold", -1)
+        dev.set_option("schur_chol", -1)
+    Amat = np.stack([model.A[0][k + 1].toarray() for k in range(nvar)])
+    assert relerr(H, _brute_H(Amat, W)) < 1e-12
+
+
+def test_chol_path_two_blocks_and_switching(dev):
+    """Two dense LMI blocks (sides 40 and 150) through the Cholesky path, then the same context switches to
+    the W path and back: the shared T workspace changes layout between assemblies."""
+    rng = np.random.default_rng(43)
+    nvar, sizes = 20, [40, 150]
+    A = []
+    for m in sizes:
+        blk = [sp.csc_matrix((m, m))]
+        for k in range(nvar):
+            R = rng.standard_normal((m, m))
+            blk.append(sp.csc_matrix(R + R.T))
+        A.append(blk)
+    model = lo.make_model(A, np.ones(nvar), 0.0, None, None)
+    dev.set_option("dense_threshold", 1)
+    try:
+        dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    finally:
+        dev.set_option("dense_threshold", -1)
+    W = []
+    for i, m in enumerate(sizes):
+        w, g = _spd(m, 20 + i)
+        W.append(w)
+        dev.set_scaling(i, w, g)
+    Href = lo.makeBBBBs(model.n, model.nlmi, model.A, model.AA, W, model.qA, model.sigmaA)
+    Href = np.tril(Href) + np.tril(Href, -1).T
+    try:
+        for chol in (1, 0, 1, 1):
+            dev.set_option("schur_chol", chol)
+            dev.reset_timing()
+            H = dev.schur_assemble(0, want_H=True)
+            assert dev.count("schur_chol") == 2 * chol
+            assert relerr(H, Href) < 1e-13
+    finally:
+        dev.set_option("schur_chol", -1)
+
+
+def test_chol_path_sharded_two_ranks(dev):
+    """world = 2 takes the Cholesky path too (replicated L' A_k L, owned column blocks of the rank-k
+    update): the shards glued by the exchange layout equal the one-rank matrix."""
+    import torch
+    msz, nvar = 260, 300
+    dev.synthetic_dense_model(msz, nvar, 11)
+    W, G = _spd(msz, 12)
+    dev.set_scaling(0, W, G)
+    Hfull = dev.schur_assemble(0, want_H=True)
+    parts = []
+    try:
+        for r in range(2):
+            dev.set_shard(r, 2)
+            dev.reset_timing()
+            dev.schur_assemble(0)
+            assert dev.count("schur_chol") == 1
+            buf = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
+            dev.schur_export_shard(buf)
+            parts.append(buf)
+        dev.schur_import_all(torch.cat(parts))
+        H2 = dev.schur_get()
+    finally:
+        dev.set_shard(0, 1)
+    assert relerr(H2, Hfull) < 1e-14
