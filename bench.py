@@ -4,7 +4,8 @@ synthetic dense SDP, matrix side 2000, 4000 constraints (SURVEY.md section 8d "C
 kit=0, FP64, data generated on the device (128 GB of constraint matrices).
 
 One "step" = one pass of the hot path over one iterate: assemble H (GEMM1/2/3 on the FP64
-MFMA), factor it (blocked Cholesky) and run the predictor and corrector solves.  Inputs
+MFMA; on one or two ranks through the Cholesky factor of W), factor it
+(blocked Cholesky) and run the predictor and corrector solves.  Inputs
 (constraint data, NT scaling W, right-hand sides) are resident in HBM when the timed region
 starts.  N > 1: one process per GPU (torchrun), Schur column blocks sharded block-cyclically,
 RCCL all-gather of the owned blocks before the factorisation; total work is fixed
@@ -45,11 +46,11 @@ def flops_model(msz, nvar):
     return 4.0 * nvar * msz ** 3 + float(nvar) ** 2 * msz ** 2 + nvar ** 3 / 3.0 + 8.0 * nvar ** 2
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per GEMM1 launch from the committed rocprofv3 --pmc passes (profiles/, same kernel,
-    same launch shape): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE reports half the
-    bytes of a 16 B/lane stream (MI355X_MICROARCH.md section HBM), which is what the
-    `buffer_load_dwordx4 ... lds` staging of this kernel issues; WRITE_SIZE is exact."""
+def pmc_traffic_bytes(kernel_pat):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/,
+    same command, same launch shape): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE reports
+    half the bytes of a 16 B/lane stream (MI355X_MICROARCH.md section HBM), which is what the direct-to-LDS
+    staging of these kernels issues; WRITE_SIZE is exact."""
     import csv
     import glob
     best = None
@@ -57,7 +58,7 @@ def pmc_traffic_bytes():
         vals = {}
         try:
             for r in csv.DictReader(open(f)):
-                if "gemm_f64_lds_kernel<false>" in r.get("kernel", "") and r.get("counter") in ("FETCH_SIZE", "WRITE_SIZE"):
+                if kernel_pat in r.get("kernel", "") and r.get("counter") in ("FETCH_SIZE", "WRITE_SIZE"):
                     vals[r["counter"]] = float(r["mean"])
         except (OSError, ValueError, KeyError):      # a malformed summary must never take the bench line down
             continue
@@ -223,17 +224,40 @@ def main():
         dist.all_gather_object(chks, chk)
         assert all(c_ == chks[0] for c_ in chks), f"ranks disagree on dely: {chks}"
     if rank == 0:
-        # dominant kernel: GEMM1  P_k = A_k W  (gemm_f64_kernel<128,128,...>, batched)
-        n1 = max(1, dev.count("gemm1"))
-        t1 = dev.timing("gemm1") / n1                               # ms per launch (HIP events)
         from loraine_jl_amd.sharding import owned_columns
-        nown = len(owned_columns(nvar, rank, world, bs=dev.shard_bs()))
-        launches_per_step = n1 / args.steps
-        units_per_launch = nown / launches_per_step                 # constraint matrices per launch
-        alg_flops_launch = 2.0 * msz ** 3 * units_per_launch
+        own = owned_columns(nvar, rank, world, bs=dev.shard_bs())
+        nown = len(own)
+        chol_path = dev.count("schur_chol") > 0
+        per_step = {k: dev.timing(k) / args.steps for k in ("gemm1", "gemm2", "gemm3")}
+        dom = max(per_step, key=per_step.get)                       # dominant kernel of this run
+        nl = max(1, dev.count(dom))
+        t1 = dev.timing(dom) / nl                                   # ms per launch (HIP events on the library's stream)
+        launches_per_step = nl / args.steps
+        # algorithmic flop of one launch = flop the formulation needs (no tile padding, symmetry and
+        # triangularity used) for the units the launch processes
+        if dom == "gemm3":
+            # packed-symmetric inner products <.,.> of msz x msz symmetric matrices: msz (msz + 1) flop per
+            # Schur entry; units = lower-triangle entries of the owned columns (position space)
+            entries = float(sum(nvar - int(j) for j in own))
+            alg_flops_launch = entries * msz * (msz + 1.0) / launches_per_step
+            kname = ("gemm_f64_kseg_lds_kernel<true> GEMM3' H[j,i] = <L'A_jL, L'A_iL> (packed lower tiles, split-K)"
+                     if chol_path else "gemm_f64_kseg_lds_kernel<false> GEMM3 H[j,i] = <A_j, W A_i W> (lower tiles, split-K)")
+            kpat = "gemm_f64_kseg_lds_kernel<true>" if chol_path else "gemm_f64_kseg_lds_kernel<false>"
+        elif dom == "gemm1":
+            units_per_launch = (nvar if chol_path else nown) / launches_per_step      # constraint matrices per launch
+            alg_flops_launch = (2.0 / 3.0 if chol_path else 2.0) * msz ** 3 * units_per_launch
+            kname = ("gemm_f64_lds_kernel<false> GEMM1' P_k = A_k L (lower tiles, triangular K)" if chol_path
+                     else "gemm_f64_lds_kernel<false> GEMM1 P_k = A_k W (batched, direct-to-LDS staging)")
+            kpat = "gemm_f64_lds_kernel<false>"
+        else:
+            units_per_launch = (nvar if chol_path else nown) / launches_per_step
+            alg_flops_launch = (1.0 / 3.0 if chol_path else 1.0) * msz ** 3 * units_per_launch
+            kname = "gemm_f64_lds_kernel<true> GEMM2 (lower tiles)"
+            kpat = "gemm_f64_lds_kernel<true>"
         achieved = alg_flops_launch / (t1 * 1e-3) / 1e12
         probe = dev.mfma_f64_peak()
-        phases = {k: dev.timing(k) / args.steps for k in ("gemm1", "gemm2", "gemm3", "assemble", "factor", "solve")}
+        phases = {k: dev.timing(k) / args.steps
+                  for k in ("wchol", "gemm1", "gemm2", "gemm3", "reduce3", "assemble", "factor", "solve")}
         out = {
             "metric": "ms/IP-iteration (Schur assembly + solve), dense SDP n=2000 m=4000",
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,11 +268,13 @@ def main():
                        "msz": msz, "nvar": nvar, "seed": args.seed,
                        "parallelism": "1 GPU" if world == 1 else f"Schur column blocks over {world} GPUs + RCCL all-gather"},
             "algorithmic_tflops": flops_model(msz, nvar) / (ms_per_step * 1e-3) / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f64_lds_kernel<false> GEMM1 P_k = A_k W (batched, direct-to-LDS staging)",
+            "assembly_path": "cholesky (H_ij = <L'A_iL, L'A_jL>, W = LL')" if chol_path else "T_k = W A_k W",
+            "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic_bytes() if (msz, world) == (2000, 1) else None,
-                         "peak_probe": probe, "avg_launch_ms": t1, "launches_per_step": launches_per_step},
+                         "traffic": pmc_traffic_bytes(kpat) if (msz, nvar, world) == (2000, 4000, 1) else None,
+                         "peak_probe": probe, "avg_launch_ms": t1, "launches_per_step": launches_per_step,
+                         "alg_flops_per_launch": alg_flops_launch},
             "phase_ms_per_step": phases,
             "dely_checksum": chk,
             "data_gen_s": t_gen,

@@ -400,9 +400,11 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap, bool* done) 
     g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = nsd;
     g3.ksplit = ksplit; g3.sCs = (long)M * N;
     LRN_TRY(gemm(c->stream, g3));
+    toc(c, "gemm3");
+    tic(c);
     hipLaunchKernelGGL(reduce_slabs_tri_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,
                        c->slabs.as<double>(), (long)M * N, ksplit, nsd, M, N, Hd + (long)s0 + (long)s0 * ldh, ldh);
-    toc(c, "gemm3");
+    toc(c, "reduce3");
   }
   if (!c->pos_space)
     hipLaunchKernelGGL(scatter_add_lower_kernel, dim3(nblocks((long)nd * nd)), dim3(256), 0, c->stream, Hd, nd,

@@ -23,7 +23,8 @@ rec = dict(msz=msz, nvar=nvar, iters=len(tr), status=solver.status, wall_s=wall,
            ms_per_iter=float(np.mean([x["itertime"] for x in tr[1:]]) * 1e3),
            gpu_ms={k: float(np.mean([x["gpu_ms"][k] for x in tr[1:]])) for k in tr[0]["gpu_ms"]},
            find_step_ms=float(np.mean([x.get("find_step_ms", 0.0) for x in tr[1:]])),
-           svd_sweeps=[x["svd_sweeps"] for x in tr])
+           svd_sweeps=[x["svd_sweeps"] for x in tr],
+           schur_chol=[x["schur_chol"] for x in tr], wchol_fail=[x["wchol_fail"] for x in tr])
 print(json.dumps(rec), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(dict(rec, trace=[{k: v for k, v in x.items() if k != "errs"} for x in tr]),

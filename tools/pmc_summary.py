@@ -35,12 +35,13 @@ def get(kpat, cname):
         if kpat in r["kernel"] and r["counter"] == cname:
             return r
     return None
-k1 = "gemm_f64_lds_kernel<false>"
-mf, gui = get(k1, "SQ_VALU_MFMA_BUSY_CYCLES"), get(k1, "GRBM_GUI_ACTIVE")
-if mf and gui:
-    cyc = gui["mean"] / 8.0
-    print("GEMM1: clock %.2f GHz, MFMA busy %.1f %%" % (cyc / gui["mean_duration_ns"], 100 * mf["mean"] / (cyc * 1024)))
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    r = get(k1, c)
-    if r:
-        print("GEMM1 %s = %.1f MB per launch (raw counter, KB units)" % (c, r["mean"] / 1024.0))
+for k1, label in (("gemm_f64_kseg_lds_kernel<true>", "GEMM3'"), ("gemm_f64_lds_kernel<false>", "GEMM1'"),
+                  ("gemm_f64_lds_kernel<true>", "GEMM2'")):
+    mf, gui = get(k1, "SQ_VALU_MFMA_BUSY_CYCLES"), get(k1, "GRBM_GUI_ACTIVE")
+    if mf and gui:
+        cyc = gui["mean"] / 8.0
+        print("%s: clock %.2f GHz, MFMA busy %.1f %%" % (label, cyc / gui["mean_duration_ns"], 100 * mf["mean"] / (cyc * 1024)))
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        r = get(k1, c)
+        if r:
+            print("%s %s = %.1f MB per launch (raw counter, KB units)" % (label, c, r["mean"] / 1024.0))

@@ -14,13 +14,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3
 tail -2 $O/prof_stats_bench.log
 find $O/prof_stats -name "*stats*.csv" | head
 echo "== pmc pass 1 (mfma busy / clock)"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/prof_pmc1 -- python3 bench.py --nvar 512 --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_pmc1.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/prof_pmc1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_pmc1.log 2>&1
 tail -2 $O/prof_pmc1.log
 echo "== pmc pass 2 (fetch)"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_pmc2 -- python3 bench.py --nvar 512 --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_pmc2 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_pmc2.log 2>&1
 tail -2 $O/prof_pmc2.log
 echo "== pmc pass 3 (write)"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_pmc3 -- python3 bench.py --nvar 512 --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_pmc3 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_pmc3.log 2>&1
 tail -2 $O/prof_pmc3.log
 # keep only small summaries (the merge-back limit is 64 MiB)
 find $O -name "*.csv" -size +20M -delete
