@@ -228,6 +228,7 @@ def main():
         own = owned_columns(nvar, rank, world, bs=dev.shard_bs())
         nown = len(own)
         chol_path = dev.count("schur_chol") > 0
+        via_l = dev.count("schur_via_l") > 0                        # W path with T_k = L (L'A_kL) L'  (>= 3 ranks)
         per_step = {k: dev.timing(k) / args.steps for k in ("gemm1", "gemm2", "gemm3")}
         dom = max(per_step, key=per_step.get)                       # dominant kernel of this run
         nl = max(1, dev.count(dom))
@@ -245,14 +246,16 @@ def main():
             kpat = "gemm_f64_kseg_lds_kernel<true>" if chol_path else "gemm_f64_kseg_lds_kernel<false>"
         elif dom == "gemm1":
             units_per_launch = (nvar if chol_path else nown) / launches_per_step      # constraint matrices per launch
-            alg_flops_launch = (2.0 / 3.0 if chol_path else 2.0) * msz ** 3 * units_per_launch
+            alg_flops_launch = (2.0 / 3.0 if chol_path else (1.0 if via_l else 2.0)) * msz ** 3 * units_per_launch
             kname = ("gemm_f64_lds_kernel<false> GEMM1' P_k = A_k L (lower tiles, triangular K)" if chol_path
-                     else "gemm_f64_lds_kernel<false> GEMM1 P_k = A_k W (batched, direct-to-LDS staging)")
+                     else ("gemm_f64_lds_kernel P_k = A_k L and At_k = L'P_k (timed together; lower tiles, triangular K)" if via_l
+                           else "gemm_f64_lds_kernel<false> GEMM1 P_k = A_k W (batched, direct-to-LDS staging)"))
             kpat = "gemm_f64_lds_kernel<false>"
         else:
             units_per_launch = (nvar if chol_path else nown) / launches_per_step
             alg_flops_launch = (1.0 / 3.0 if chol_path else 1.0) * msz ** 3 * units_per_launch
-            kname = "gemm_f64_lds_kernel<true> GEMM2 (lower tiles)"
+            kname = ("gemm_f64_lds_kernel Q_k = L At_k and T_k = Q_k L' (timed together; lower tiles, triangular K)" if via_l
+                     else "gemm_f64_lds_kernel<true> GEMM2 (lower tiles)")
             kpat = "gemm_f64_lds_kernel<true>"
         achieved = alg_flops_launch / (t1 * 1e-3) / 1e12
         probe = dev.mfma_f64_peak()
@@ -268,7 +271,8 @@ def main():
                        "msz": msz, "nvar": nvar, "seed": args.seed,
                        "parallelism": "1 GPU" if world == 1 else f"Schur column blocks over {world} GPUs + RCCL all-gather"},
             "algorithmic_tflops": flops_model(msz, nvar) / (ms_per_step * 1e-3) / 1e12,
-            "assembly_path": "cholesky (H_ij = <L'A_iL, L'A_jL>, W = LL')" if chol_path else "T_k = W A_k W",
+            "assembly_path": ("cholesky (H_ij = <L'A_iL, L'A_jL>, W = LL')" if chol_path
+                              else ("T_k = L (L'A_kL) L', W = LL'" if via_l else "T_k = W A_k W")),
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,

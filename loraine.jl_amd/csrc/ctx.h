@@ -82,7 +82,7 @@ struct lrn_ctx {
   bool have_H = false, have_L = false;
   bool H_shifted = false;     // lrn_schur_add_diag since the last assembly: strict Cholesky only
   // assembly workspaces
-  lrn::DBuf P, T, slabs, Hd, BG;
+  lrn::DBuf P, P2, T, slabs, Hd, BG;
   lrn::DBuf m0, m1, m2, cgbuf;   // msz^2 work matrices (mat-vec / rhs), PCG vectors
   int T_m = 0;                 // matrix side and block the T workspace was last laid out for
   const void* T_owner = nullptr;

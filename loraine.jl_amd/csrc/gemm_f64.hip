@@ -86,6 +86,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     if (kend > d.K) kend = d.K;
     if (d.flags & GEMM_KFROM_N) kcur = n0;          // (ksplit == 1: checked by the launcher)
     if (d.flags & GEMM_KFROM_M) kcur = m0;
+    if ((d.flags & GEMM_KTO_N) && kend > n0 + BN) kend = n0 + BN;
+    if ((d.flags & GEMM_KTO_M) && kend > m0 + BM) kend = m0 + BM;
   }
 
   // ---- per-thread staging geometry
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   const bool sq = EPI && (d.flags & GEMM_SQUARE);
   // packed lower-tile C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
   const bool pk = EPI && (d.flags & GEMM_C_PACKED);
+  const bool mir = EPI && (d.flags & GEMM_C_MIRROR) && (tm != tn);
   const int pkS = packed_S(d.pk_m);
   const long pkKd = packed_diag_elems(d.pk_m > 0 ? d.pk_m : 1);
 #pragma unroll
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
           double* c = pk ? Cg + packed_lower_offset(n, m, pkS, pkKd) : Cg + (long)m * d.sCm + (long)n * d.sCn;
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
+          if (mir) Cg[(long)n * d.sCm + (long)m * d.sCn] = v;
         }
       }
 }
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     // triangular-K products: the tiles of one matrix differ in K length, and with nwg % 8 == 0 every
     // XCD would get the same run of the list for every batch element -- rotate the runs over the XCDs
-    if ((d.flags & (GEMM_KFROM_N | GEMM_KFROM_M)) && r == 0) {
+    if ((d.flags & (GEMM_KFROM_N | GEMM_KFROM_M | GEMM_KTO_N | GEMM_KTO_M)) && r == 0) {
       xcd = (xcd + (int)blockIdx.z) & 7;
       swz = xcd * q + (bid >> 3);
     }
@@ -276,7 +280,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   const int ma = m0 + 2 * lane, nb = n0 + 2 * lane;
   const unsigned offA = ma < d.M ? (unsigned)ma * 8u : 0x80000000u;
   const unsigned offB = nb < d.N ? (unsigned)nb * 8u : 0x80000000u;
-  const int nk = (d.K + BK - 1) / BK;
+  int kend = d.K;       // triangular operand: the K loop ends with the tile (tile origins are multiples of 128)
+  if ((d.flags & GEMM_KTO_N) && kend > n0 + BN) kend = n0 + BN;
+  if ((d.flags & GEMM_KTO_M) && kend > m0 + BM) kend = m0 + BM;
+  const int nk = (kend + BK - 1) / BK;
 
   v4f64 acc[TM][TN];
 #pragma unroll
@@ -330,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   const bool sq = EPI && (d.flags & GEMM_SQUARE);
   // packed lower-tile C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
   const bool pk = EPI && (d.flags & GEMM_C_PACKED);
+  const bool mir = EPI && (d.flags & GEMM_C_MIRROR) && (tm != tn);
   const int pkS = packed_S(d.pk_m);
   const long pkKd = packed_diag_elems(d.pk_m > 0 ? d.pk_m : 1);
 #pragma unroll
@@ -346,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
           double* c = pk ? Cg + packed_lower_offset(n, m, pkS, pkKd) : Cg + (long)m * d.sCm + (long)n * d.sCn;
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
+          if (mir) Cg[(long)n * d.sCm + (long)m * d.sCn] = v;
         }
       }
 }
@@ -546,6 +555,8 @@ int gemm(hipStream_t st, const GemmDesc& din) {
     swapped = true;
     if (d.flags & GEMM_KFROM_N) d.flags = (d.flags & ~GEMM_KFROM_N) | GEMM_KFROM_M;
     else if (d.flags & GEMM_KFROM_M) d.flags = (d.flags & ~GEMM_KFROM_M) | GEMM_KFROM_N;
+    if (d.flags & GEMM_KTO_N) d.flags = (d.flags & ~GEMM_KTO_N) | GEMM_KTO_M;
+    else if (d.flags & GEMM_KTO_M) d.flags = (d.flags & ~GEMM_KTO_M) | GEMM_KTO_N;
     std::swap(d.A, d.B);
     std::swap(d.bA, d.bB);
     long sAm = d.sBn, sAk = d.sBk, sBk = d.sAk, sBn = d.sAm;
@@ -558,13 +569,14 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   const bool tri = d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER);
   const bool kflat = d.flags & GEMM_KFLAT;
   const bool kseg = (d.flags & GEMM_KSEG_TRI) || kflat;
-  const bool kfrom = d.flags & (GEMM_KFROM_N | GEMM_KFROM_M);
+  const bool kfrom = d.flags & (GEMM_KFROM_N | GEMM_KFROM_M | GEMM_KTO_N | GEMM_KTO_M);   // triangular K ranges
+  if ((d.flags & GEMM_C_MIRROR) && (d.M != d.N || !tri || d.beta != 0.0)) return LRN_ERR_ARG;
   if (kfrom && (d.ksplit != 1 || d.M != d.N || d.M != d.K || kseg)) return LRN_ERR_ARG;
   if ((d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)) return LRN_ERR_ARG;
   // tile choice: 128x128 unless the problem is too small to fill the chip with it
   long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit;
   bool small = (d.flags & GEMM_SMALL_TILE) ||
-               (t128 < 256 && !(d.flags & (GEMM_OFFDIAG_X2 | GEMM_C_PACKED)) && !kseg && !kfrom);
+               (t128 < 256 && !(d.flags & (GEMM_OFFDIAG_X2 | GEMM_C_PACKED | GEMM_C_MIRROR)) && !kseg && !kfrom);
   const int BMv = small ? 64 : 128;
   p.tilesM = (d.M + BMv - 1) / BMv;
   p.tilesN = (d.N + BMv - 1) / BMv;
@@ -610,7 +622,7 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   const bool bkc = (d.sBk == 1 && d.sBn != 1);
   dim3 grid(ntile, 1, d.batch * d.ksplit);
   if (grid.z > 65535) return LRN_ERR_ARG;
-  const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE | GEMM_C_PACKED);
+  const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE | GEMM_C_PACKED | GEMM_C_MIRROR);
   if (kflat) {
     hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true>), grid, dim3(256), 0, st, p);
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;

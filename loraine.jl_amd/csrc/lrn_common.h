@@ -54,6 +54,9 @@ enum : int {
   GEMM_KFROM_M = 128,      // same with the m-tile (op(A)[m][k] = 0 for k < m)
   GEMM_C_PACKED = 256,     // C is an msz x msz symmetric matrix stored as packed lower 128-tiles
                            // (packed_lower_offset below; pk_m, pk_S); needs sCm == 1 on entry
+  GEMM_KTO_N = 1024,       // the K loop ends with the n-tile (k < n0 + 128): op(B)[k][n] = 0 for k > n
+  GEMM_KTO_M = 2048,       // same with the m-tile (op(A)[m][k] = 0 for k > m)
+  GEMM_C_MIRROR = 4096,    // off-diagonal tiles are also stored transposed (C symmetric, computed one-sided)
   GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower-tile layout;
                            // the first kflat_nsd splits cover the diagonal tiles [0, kflat_diag), the
                            // others the strictly-lower tiles [kflat_diag, K)

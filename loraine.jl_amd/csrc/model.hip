@@ -169,7 +169,7 @@ void lrn_free_model(lrn_ctx* c) {
   for (auto& b : c->lmi) free_block(b);
   c->lmi.clear();
   for (DBuf* d : {&c->cl_ptr, &c->cl_row, &c->cl_val, &c->lin_xs, &c->H, &c->L, &c->Linv, &c->cholwork,
-                  &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->T, &c->slabs, &c->Hd, &c->BG, &c->m0, &c->m1, &c->m2, &c->cgbuf, &c->cl_rown,
+                  &c->v0, &c->v1, &c->v2, &c->v3, &c->P, &c->P2, &c->T, &c->slabs, &c->Hd, &c->BG, &c->m0, &c->m1, &c->m2, &c->cgbuf, &c->cl_rown,
                   &c->hdiag, &c->wchol, &c->lp_r, &c->lp_c, &c->lp_ptr, &c->lp_l, &c->lp_w, &c->cr_ptr, &c->cr_col, &c->cr_val})
     release(*d);
   c->T_m = 0;

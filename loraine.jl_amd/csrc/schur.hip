@@ -299,13 +299,20 @@ static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
   return true;
 }
 
-// returns LRN_OK with *done = false when W could not be factored (caller falls back)
-static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap, bool* done) {
-  const int m = b.msz, nd = b.nd, n = c->nvar;
+// W = L L' for the assembly: c->wchol = [ L (col-major, strict upper part zeroed) | Ut = L' with explicit zeros |
+// potrf work ].  *ok = false when W is not numerically positive definite.
+__global__ void tril_inplace_kernel(double* __restrict__ L, int m) {
+  long total = (long)m * m;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % m), j = (int)(e / m);
+    if (i < j) L[e] = 0.0;
+  }
+}
+
+static int factor_w(lrn_ctx* c, LmiBlock& b, bool* ok) {
+  const int m = b.msz;
   const long mm = (long)m * m;
-  const long Kp = packed_total_elems(m), Kd = packed_diag_elems(m);
-  *done = false;
-  // ---- W = L L'
+  *ok = false;
   const size_t linv = chol_linv_doubles(m);
   LRN_TRY(ensure(c, c->wchol, (2 * (size_t)mm + linv + (size_t)m * CHOL_NB) * 8));
   double* Lw = c->wchol.as<double>();
@@ -324,7 +331,18 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap, bool* done) 
     return LRN_OK;
   }
   hipLaunchKernelGGL(transpose_lower_kernel, dim3((m + 31) / 32, (m + 31) / 32), dim3(256), 0, c->stream, Lw, m, Ut);
+  hipLaunchKernelGGL(tril_inplace_kernel, dim3(nblocks(mm)), dim3(256), 0, c->stream, Lw, m);
   toc(c, "wchol");
+  *ok = true;
+  return LRN_OK;
+}
+
+// (W = L L' already in c->wchol, factor_w)
+static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
+  const int m = b.msz, nd = b.nd, n = c->nvar;
+  const long mm = (long)m * m;
+  const long Kp = packed_total_elems(m), Kd = packed_diag_elems(m);
+  double* Ut = c->wchol.as<double>() + mm;
   // ---- workspaces: P (batch of row-major A_k L), T (all At_k, packed)
   LRN_TRY(ensure(c, c->P, (size_t)P_cap * mm * 8));
   const void* t_before = c->T.p;
@@ -410,21 +428,24 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap, bool* done) 
     hipLaunchKernelGGL(scatter_add_lower_kernel, dim3(nblocks((long)nd * nd)), dim3(256), 0, c->stream, Hd, nd,
                        b.hidx.as<int>(), H, n);
   c->counts["schur_chol"] += 1;
-  *done = true;
   return LRN_OK;
 }
 
 static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
-  {
-    long pcap = 0;
-    if (chol_path_applicable(c, b, &pcap)) {
-      bool done = false;
-      LRN_TRY(assemble_dense_chol(c, b, pcap, &done));
-      if (done) return LRN_OK;
-    }
-  }
   const int m = b.msz, nd = b.nd, n = c->nvar;
   const long mm = (long)m * m;
+  // Both fast paths need W = L L'.  via_l: the W path below forms T_k = L (L' A_k L) L' on triangular K ranges
+  // (4 products, 2 msz^3 flop) instead of W (A_k W) (2 products, 3 msz^3); this is what ranks of a >= 3-GPU job and
+  // blocks with sparse constraints run.  option schur_chol: -1 auto, 0 never factor W, 1 as auto without the size
+  // thresholds, 2 T-via-L only.
+  bool via_l = false;
+  {
+    long pcap = 0;
+    const bool want_chol = opt_schur_chol != 2 && chol_path_applicable(c, b, &pcap);
+    const bool want_via_l = opt_schur_chol > 0 || (opt_schur_chol < 0 && m >= 256);
+    if (want_chol || want_via_l) LRN_TRY(factor_w(c, b, &via_l));
+    if (via_l && want_chol) return assemble_dense_chol(c, b, pcap);
+  }
   double* W = b.W.as<double>();
   double* Ad = b.Adense.as<double>();
   double* H = c->H.as<double>();
@@ -436,7 +457,8 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
     long pcap = opt_p_batch > 0 ? opt_p_batch : pick_p_batch(m, nd);
     if (pcap > nd) pcap = nd;
     // memory that is free now plus what the shared workspaces already hold
-    double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes) * 0.80 - (double)pcap * mm * 8.0 - 1.5e9;
+    double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes + (double)c->P2.bytes) * 0.80 -
+                   2.0 * (double)pcap * mm * 8.0 - 1.5e9;
     long tcap = (long)(avail / ((double)mm * 8.0));
     if (opt_t_batch > 0) tcap = opt_t_batch;
     if (tcap > nd) tcap = nd;
@@ -480,7 +502,47 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   }
   for (auto& g : groups) {
     const int s0 = g.first, s1 = g.second, ns = s1 - s0;
-    for (int a = s0; a < s1; a += (int)P_cap) {
+    for (int a = s0; a < s1 && via_l; a += (int)P_cap) {
+      const int nb = std::min((int)P_cap, s1 - a);
+      double* Lw = c->wchol.as<double>();
+      double* Ut = Lw + mm;
+      LRN_TRY(ensure(c, c->P2, (size_t)P_cap * mm * 8));
+      double* P2 = c->P2.as<double>();
+      tic(c);
+      GemmDesc g1;   // P = A_a L, row-major, tiles i >= j, K from the tile's column origin
+      g1.A = Ad + (long)a * mm; g1.sAm = 1; g1.sAk = m; g1.bA = mm;
+      g1.B = Ut; g1.sBk = m; g1.sBn = 1; g1.bB = 0;
+      g1.C = P; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
+      g1.M = g1.N = g1.K = m; g1.batch = nb;
+      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N;
+      LRN_TRY(gemm(c->stream, g1));
+      GemmDesc g2;   // At = L' P, tiles i >= j (K from the tile's row origin), mirrored: full symmetric, col-major
+      g2.A = Ut; g2.sAm = 1; g2.sAk = m; g2.bA = 0;
+      g2.B = P; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
+      g2.C = P2; g2.sCm = 1; g2.sCn = m; g2.bC = mm;
+      g2.M = g2.N = g2.K = m; g2.batch = nb;
+      g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_MIRROR;
+      LRN_TRY(gemm(c->stream, g2));
+      toc(c, "gemm1");
+      tic(c);
+      GemmDesc g3;   // Q = L At, tiles i >= j, K up to the end of the tile's rows; col-major into P
+      g3.A = Lw; g3.sAm = 1; g3.sAk = m; g3.bA = 0;
+      g3.B = P2; g3.sBk = m; g3.sBn = 1; g3.bB = mm;            // At symmetric: At[k,n] read as At[n + k*m]
+      g3.C = P; g3.sCm = 1; g3.sCn = m; g3.bC = mm;
+      g3.M = g3.N = g3.K = m; g3.batch = nb;
+      g3.flags = GEMM_TRI_LOWER | GEMM_KTO_M;
+      LRN_TRY(gemm(c->stream, g3));
+      GemmDesc g4;   // T = Q L', lower tiles (strictly-lower x2), K up to the end of the tile's columns
+      g4.A = P; g4.sAm = 1; g4.sAk = m; g4.bA = mm;
+      g4.B = Lw; g4.sBk = m; g4.sBn = 1; g4.bB = 0;             // op(B)[k][j] = L[j,k]
+      g4.C = T + (long)(a - s0) * mm; g4.sCm = 1; g4.sCn = m; g4.bC = mm;
+      g4.M = g4.N = g4.K = m; g4.batch = nb;
+      g4.flags = GEMM_TRI_LOWER | GEMM_OFFDIAG_X2 | GEMM_KTO_N;
+      LRN_TRY(gemm(c->stream, g4));
+      toc(c, "gemm2");
+      c->counts["schur_via_l"] += 1;
+    }
+    for (int a = s0; a < s1 && !via_l; a += (int)P_cap) {
       int nb = std::min((int)P_cap, s1 - a);
       tic(c);
       GemmDesc g1;   // P = A_a W, stored row-major (P^T) so that GEMM2 reads it n-contiguous;

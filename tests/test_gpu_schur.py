@@ -98,11 +98,12 @@ def _dense_model(msz, nvar, seed, density=1.0):
     return lo.make_model(A, rng.standard_normal(nvar), 0.0, None, None)
 
 
-@pytest.mark.parametrize("chol", [0, 1])
+@pytest.mark.parametrize("chol", [0, 1, 2])
 @pytest.mark.parametrize("msz,nvar", [(96, 40), (300, 130), (257, 300), (16, 5), (130, 20), (333, 37)])
 def test_dense_mfma_path_matches_oracle(dev, msz, nvar, chol):
     """The C4-shaped path: every constraint dense -> GEMM1/GEMM2/GEMM3; chol=0: T_k = W A_k W,
-    chol=1: the Cholesky path (L' A_k L on triangular K ranges, packed lower tiles, weighted slabs)."""
+    chol=1: the Cholesky path (L' A_k L on triangular K ranges, packed lower tiles, weighted slabs),
+    chol=2: T_k = L (L' A_k L) L' (four triangular products, mirrored store) feeding the W path's GEMM3."""
     model = _dense_model(msz, nvar, msz + nvar)
     W, G = _spd(msz, 5)
     dev.set_option("dense_threshold", 1)             # force the MFMA path regardless of the cost model
@@ -112,7 +113,8 @@ def test_dense_mfma_path_matches_oracle(dev, msz, nvar, chol):
         dev.set_scaling(0, W, G)
         dev.reset_timing()
         H = dev.schur_assemble(0, want_H=True)
-        assert dev.count("schur_chol") == chol
+        assert dev.count("schur_chol") == (1 if chol == 1 else 0)
+        assert (dev.count("schur_via_l") > 0) == (chol == 2)
     finally:
         dev.set_option("dense_threshold", -1)
         dev.set_option("schur_chol", -1)
@@ -143,15 +145,23 @@ def test_mixed_dense_sparse_owners(dev):
     model = lo.make_model(A, rng.standard_normal(nd + ns), 0.0, None, None, kappa=30)
     W, G = _spd(msz, 9)
     dev.set_option("dense_threshold", 1000)
+    Hs = []
     try:
         _upload(dev, model)
         dev.set_scaling(0, W, G)
-        H = dev.schur_assemble(0, want_H=True)
+        for chol in (0, 2):                          # T_k = W A_k W, and T_k = L (L' A_k L) L'
+            dev.set_option("schur_chol", chol)
+            dev.reset_timing()
+            Hs.append(dev.schur_assemble(0, want_H=True))
+            assert dev.count("schur_chol") == 0 and (dev.count("schur_via_l") > 0) == (chol == 2)
     finally:
         dev.set_option("dense_threshold", -1)
+        dev.set_option("schur_chol", -1)
     Amat = np.stack([model.A[0][k + 1].toarray() for k in range(nd + ns)])
     Href = _brute_H(Amat, W)
+    H = Hs[0]
     assert relerr(H, Href) < 1e-13
+    assert relerr(Hs[1], Href) < 1e-13
     Horacle = _herm_lower(lo.makeBBBBs(model.n, 1, model.A, model.AA, [W], model.qA, model.sigmaA))
     assert relerr(Horacle, Href) < 1e-13
 
@@ -289,14 +299,19 @@ def test_chol_path_equals_w_path_midsize(dev):
     dev.reset_timing()
     H1 = dev.schur_assemble(0, want_H=True)
     assert dev.count("schur_chol") == 1              # auto: all constraints dense, one rank
-    dev.set_option("schur_chol", 0)
     try:
+        dev.set_option("schur_chol", 0)
         dev.reset_timing()
         H0 = dev.schur_assemble(0, want_H=True)
-        assert dev.count("schur_chol") == 0
+        assert dev.count("schur_chol") == 0 and dev.count("schur_via_l") == 0
+        dev.set_option("schur_chol", 2)
+        dev.reset_timing()
+        H2 = dev.schur_assemble(0, want_H=True)
+        assert dev.count("schur_chol") == 0 and dev.count("schur_via_l") > 0
     finally:
         dev.set_option("schur_chol", -1)
     assert relerr(H1, H0) < 1e-13
+    assert relerr(H2, H0) < 1e-13
     assert np.array_equal(H1, H1.T)
     A = np.stack([dev.get_constraint(0, k) for k in range(0, nvar, 50)])
     Href = _brute_H(A, W)
@@ -316,7 +331,7 @@ def test_chol_path_falls_back_when_w_is_singular(dev):
         dev.set_scaling(0, W, np.zeros((msz, msz)))
         dev.reset_timing()
         H = dev.schur_assemble(0, want_H=True)
-        assert dev.count("wchol_fail") == 1 and dev.count("schur_chol") == 0
+        assert dev.count("wchol_fail") == 1 and dev.count("schur_chol") == 0 and dev.count("schur_via_l") == 0
     finally:
         dev.set_option("dense_threshold", -1)
         dev.set_option("schur_chol", -1)
@@ -350,11 +365,11 @@ def test_chol_path_two_blocks_and_switching(dev):
     Href = lo.makeBBBBs(model.n, model.nlmi, model.A, model.AA, W, model.qA, model.sigmaA)
     Href = np.tril(Href) + np.tril(Href, -1).T
     try:
-        for chol in (1, 0, 1, 1):
+        for chol in (1, 0, 2, 1, 1):
             dev.set_option("schur_chol", chol)
             dev.reset_timing()
             H = dev.schur_assemble(0, want_H=True)
-            assert dev.count("schur_chol") == 2 * chol
+            assert dev.count("schur_chol") == (2 if chol == 1 else 0)
             assert relerr(H, Href) < 1e-13
     finally:
         dev.set_option("schur_chol", -1)
@@ -384,3 +399,33 @@ def test_chol_path_sharded_two_ranks(dev):
     finally:
         dev.set_shard(0, 1)
     assert relerr(H2, Hfull) < 1e-14
+
+
+def test_via_l_path_sharded_three_ranks(dev):
+    """world = 3: the ranks run the W path with T_k = L (L' A_k L) L' for their own columns; the shards glued by
+    the exchange layout equal the one-rank matrix (which took the Cholesky path)."""
+    import torch
+    msz, nvar = 300, 420
+    dev.synthetic_dense_model(msz, nvar, 13)
+    W, G = _spd(msz, 14, cond=1e5)
+    dev.set_scaling(0, W, G)
+    dev.reset_timing()
+    Hfull = dev.schur_assemble(0, want_H=True)
+    assert dev.count("schur_chol") == 1
+    parts = []
+    try:
+        for r in range(3):
+            dev.set_shard(r, 3)
+            dev.reset_timing()
+            dev.schur_assemble(0)
+            assert dev.count("schur_chol") == 0 and dev.count("schur_via_l") > 0
+            buf = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
+            dev.schur_export_shard(buf)
+            parts.append(buf)
+        dev.schur_import_all(torch.cat(parts))
+        H2 = dev.schur_get()
+    finally:
+        dev.set_shard(0, 1)
+    assert relerr(H2, Hfull) < 1e-13
+    A = np.stack([dev.get_constraint(0, k) for k in range(0, nvar, 60)])
+    assert relerr(H2[::60, ::60], _brute_H(A, W)) < 1e-13
