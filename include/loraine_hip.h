@@ -67,6 +67,9 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * "matvec_sparse" (0 auto / 1 dense GEMM mat-vec / 2 pattern-restricted mat-vec when every
  * constraint is sparse), "svd_sdc" (0/1,
  * experimental divide-and-conquer start of the SVD for msz >= "sdc_min"; "sdc_leaf", "sdc_l0"),
+ * "schur_chol" (dense Schur assembly through the Cholesky factor of W: -1 auto -- H_ij = <L'A_iL, L'A_jL> when
+ * every constraint of the block is dense and world <= 2, T_k = L (L'A_kL) L' otherwise, both for msz >= 256 --,
+ * 0 never (T_k = W A_k W), 1 as auto without the size threshold, 2 the T_k form only),
  * "reset_timing". */
 int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
 /* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */

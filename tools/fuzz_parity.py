@@ -63,6 +63,16 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     bad = 0
     t0 = time.time()
+    # library-wide options: FUZZ_SCHUR_CHOL=1 takes the Cholesky-factor assembly paths regardless of size
+    # (1: <L'A_iL, L'A_jL> where every constraint of a block is dense, T_k = L (L'A_kL) L' otherwise; 2: the latter
+    # only), FUZZ_DENSE=1 stores every non-empty constraint matrix dense
+    if os.environ.get("FUZZ_SCHUR_CHOL") or os.environ.get("FUZZ_DENSE"):
+        import loraine_jl_amd
+        _d = loraine_jl_amd.Device(0)
+        if os.environ.get("FUZZ_SCHUR_CHOL"):
+            _d.set_option("schur_chol", int(os.environ["FUZZ_SCHUR_CHOL"]))
+        if os.environ.get("FUZZ_DENSE"):
+            _d.set_option("dense_threshold", 1)
     for s in range(seed0, seed0 + count):
         rng = np.random.default_rng(s)
         A, b, d_lin, C_lin = random_problem(rng)
