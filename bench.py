@@ -199,6 +199,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("LRN_GEMM3_KSPLIT"):                     # experiment knob (split-K factor of GEMM3')
+        dev.set_option("gemm3_ksplit", int(os.environ["LRN_GEMM3_KSPLIT"]))
+    if os.environ.get("LRN_GEMM3_STAGGER"):
+        dev.set_option("gemm3_stagger", int(os.environ["LRN_GEMM3_STAGGER"]))
     dev.set_option("profile", 0)
     for _ in range(args.warmup):
         step()

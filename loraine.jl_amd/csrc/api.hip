@@ -20,7 +20,7 @@ extern int opt_jacobi_wgs;
 extern int opt_svd_sdc, opt_sdc_min, opt_sdc_leaf;
 extern double opt_sdc_l0;
 extern double opt_pivot_boost;
-extern int opt_schur_chol;
+extern int opt_schur_chol, opt_gemm3_ksplit, opt_gemm3_stagger;
 }
 
 extern "C" {
@@ -87,6 +87,8 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
   else if (!strcmp(key, "pivot_boost")) lrn::opt_pivot_boost = value;
   else if (!strcmp(key, "schur_chol")) lrn::opt_schur_chol = (int)value;
+  else if (!strcmp(key, "gemm3_ksplit")) lrn::opt_gemm3_ksplit = (int)value;
+  else if (!strcmp(key, "gemm3_stagger")) lrn::opt_gemm3_stagger = (int)value;
   else if (!strcmp(key, "svd_sdc")) lrn::opt_svd_sdc = (int)value;
   else if (!strcmp(key, "sdc_min")) lrn::opt_sdc_min = (int)value;
   else if (!strcmp(key, "sdc_leaf")) lrn::opt_sdc_leaf = (int)value;

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
   const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
   const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
   const bool sq = EPI && (d.flags & GEMM_SQUARE);
-  // packed lower-tile C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
+  // packed lower C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
   const bool pk = EPI && (d.flags & GEMM_C_PACKED);
   const bool mir = EPI && (d.flags & GEMM_C_MIRROR) && (tm != tn);
   const int pkS = packed_S(d.pk_m);
@@ -212,7 +212,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
         if (m < d.M && n < d.N) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
-          double* c = pk ? Cg + packed_lower_offset(n, m, pkS, pkKd) : Cg + (long)m * d.sCm + (long)n * d.sCn;
+          if (pk) {                               // 16x16 blocks on and below the diagonal only
+            if ((n >> 4) >= (m >> 4)) Cg[packed_lower_offset(n, m, pkS, pkKd)] = v;
+            continue;
+          }
+          double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
           if (mir) Cg[(long)n * d.sCm + (long)m * d.sCn] = v;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
   const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
   const bool sq = EPI && (d.flags & GEMM_SQUARE);
-  // packed lower-tile C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
+  // packed lower C (kernel n = row, kernel m = column of the symmetric matrix; tiles with tn >= tm)
   const bool pk = EPI && (d.flags & GEMM_C_PACKED);
   const bool mir = EPI && (d.flags & GEMM_C_MIRROR) && (tm != tn);
   const int pkS = packed_S(d.pk_m);
@@ -351,7 +355,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
         if (m < d.M && n < d.N) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
-          double* c = pk ? Cg + packed_lower_offset(n, m, pkS, pkKd) : Cg + (long)m * d.sCm + (long)n * d.sCn;
+          if (pk) {                               // 16x16 blocks on and below the diagonal only
+            if ((n >> 4) >= (m >> 4)) Cg[packed_lower_offset(n, m, pkS, pkKd)] = v;
+            continue;
+          }
+          double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
           if (mir) Cg[(long)n * d.sCm + (long)m * d.sCn] = v;
@@ -411,6 +419,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   int segr = FLAT ? 0 : (segc / 128) * 128;
   const int ld = d.kseg_ld;
   auto chunk_base = [&]() -> long { return FLAT ? (long)segc * BK : (long)segc * ld + segr; };
+  // FLAT: chunks of this split not yet issued.  Workgroups that share a panel (same tm or same tn) run in
+  // lock-step -- all MFMA-bound at the same rate -- and would ask L2 for the same line within the miss latency
+  // of the first request; starting each one ((tm + tn) & 7) * kstagger chunks into the split (a Latin square:
+  // distinct along a row and along a column of the super-tile) and wrapping around spreads them in time.
+  const int seg0 = segc;
+  int left = segcend - segc;
+  if (FLAT && d.kstagger > 0 && left > 0) segc = seg0 + (int)(((long)((tm + tn) & 7) * d.kstagger) % left);
 
   v4f64 acc[TM][TN];
 #pragma unroll
@@ -431,13 +446,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
     }
   };
   auto next_chunk = [&]() {
-    if (FLAT) { ++segc; return; }
+    if (FLAT) {
+      --left;
+      if (++segc == segcend) segc = seg0;
+      return;
+    }
     segr += BK;
     if (segr >= ld) { ++segc; segr = (segc / 128) * 128; }
   };
 
   const int fr = lane & 15, fk = lane >> 4;
-  bool more = segc < segcend;
+  bool more = FLAT ? left > 0 : segc < segcend;
   if (more) {
     issue(chunk_base(), 0);
     next_chunk();
@@ -445,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   __syncthreads();
   int cur = 0;
   while (more) {
-    const bool have_next = segc < segcend;
+    const bool have_next = FLAT ? left > 0 : segc < segcend;
     if (have_next) {
       issue(chunk_base(), cur ^ 1);
       next_chunk();

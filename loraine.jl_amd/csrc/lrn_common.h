@@ -52,41 +52,43 @@ enum : int {
   GEMM_KFROM_N = 64,       // the K loop starts at the first column of the n-tile: op(B)[k][n] = 0 for
                            // k < n (B is the transposed lower Cholesky factor); forces the 128 tile
   GEMM_KFROM_M = 128,      // same with the m-tile (op(A)[m][k] = 0 for k < m)
-  GEMM_C_PACKED = 256,     // C is an msz x msz symmetric matrix stored as packed lower 128-tiles
-                           // (packed_lower_offset below; pk_m, pk_S); needs sCm == 1 on entry
+  GEMM_C_PACKED = 256,     // C is an msz x msz symmetric matrix stored in the packed lower layout (16x16 blocks
+                           // on and below the diagonal, packed_lower_offset below; pk_m); needs sCm == 1 on entry
   GEMM_KTO_N = 1024,       // the K loop ends with the n-tile (k < n0 + 128): op(B)[k][n] = 0 for k > n
   GEMM_KTO_M = 2048,       // same with the m-tile (op(A)[m][k] = 0 for k > m)
   GEMM_C_MIRROR = 4096,    // off-diagonal tiles are also stored transposed (C symmetric, computed one-sided)
-  GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower-tile layout;
-                           // the first kflat_nsd splits cover the diagonal tiles [0, kflat_diag), the
-                           // others the strictly-lower tiles [kflat_diag, K)
+  GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower layout;
+                           // the first kflat_nsd splits cover the diagonal blocks [0, kflat_diag), the
+                           // others the strictly-lower blocks [kflat_diag, K)
 };
 
-// ---------------------------------------------------------------- packed lower-tile layout
-// A symmetric msz x msz matrix of which only the 128-tiles on and below the diagonal are kept
-// (schur.hip, Cholesky path: At_k = L' A_k L).  S = msz rounded up to 16.  Flat index space:
-//   [0, Kd)   diagonal tiles, tile t at t*128*128, column-major with column length min(128, S-128t)
-//   [Kd, Kp)  per column c (tile t): rows 128(t+1) .. S-1, contiguous
-// Every column piece is a multiple of 16 doubles, rows >= msz are never written (stay zero), so a
-// K walk in chunks of 16 never straddles the two regions.  <X,Y> = sum over [0,Kd) + 2 * sum over [Kd,Kp).
+// ---------------------------------------------------------------- packed lower layout
+// A symmetric msz x msz matrix of which only the 16x16 blocks on and below the diagonal are kept
+// (schur.hip, Cholesky path: At_k = L' A_k L).  S = msz rounded up to 16, column c lies in block column
+// q = c / 16.  Flat index space:
+//   [0, Kd)   Kd = 16 msz: column c at 16 c holds rows 16q .. 16q+15 (the diagonal block, both triangles)
+//   [Kd, Kp)  column c: rows 16(q+1) .. S-1, contiguous
+// Every column piece is a multiple of 16 doubles and rows >= msz are never written (stay zero), so a K walk
+// in chunks of 16 never straddles the two regions.  <X,Y> = sum over [0,Kd) + 2 * sum over [Kd,Kp).
 __host__ __device__ inline int packed_S(int m) { return (m + 15) & ~15; }
-__host__ __device__ inline long packed_diag_elems(int m) {
-  const int nt = (m + 127) >> 7, S = packed_S(m);
-  const int sl = S - 128 * (nt - 1) < 128 ? S - 128 * (nt - 1) : 128;
-  return (long)(nt - 1) * 16384 + (long)(m - 128 * (nt - 1)) * sl;
+__host__ __device__ inline long packed_diag_elems(int m) { return 16L * m; }
+// number of [Kd,Kp) elements in the columns before c
+__host__ __device__ inline long packed_off_base(int c, int S) {
+  const long q = c >> 4;
+  return 16L * (q * S - 8L * q * (q + 1)) + (long)(c - 16 * q) * (S - 16 * (q + 1));
 }
-__host__ __device__ inline long packed_off_base(int t, int S) { return 128L * ((long)t * S - 64L * t * (t + 1)); }
-__host__ __device__ inline long packed_total_elems(int m) {
-  return packed_diag_elems(m) + packed_off_base(((m + 127) >> 7) - 1, packed_S(m));
+__host__ __device__ inline long packed_total_elems(int m) { return packed_diag_elems(m) + packed_off_base(m, packed_S(m)); }
+// row stride of an array of packed matrices: Kp padded to an ODD number of 128-byte lines (rows of a panel then
+// start in different 256-byte phases; measured at C4: no effect on the L2 hit rate or the time, kept as hygiene)
+__host__ __device__ inline long packed_ld(int m) {
+  const long kp = packed_total_elems(m);
+  return ((kp >> 4) & 1) ? kp : kp + 16;
 }
-// offset of element (r, c), r / 128 >= c / 128
+// offset of element (r, c), r / 16 >= c / 16
 __host__ __device__ inline long packed_lower_offset(int r, int c, int S, long Kd) {
-  const int t = c >> 7, cl = c & 127;
-  if ((r >> 7) == t) {
-    const int sl = S - 128 * t < 128 ? S - 128 * t : 128;
-    return (long)t * 16384 + (long)cl * sl + (r - 128 * t);
-  }
-  return Kd + packed_off_base(t, S) + (long)cl * (S - 128 * (t + 1)) + (r - 128 * (t + 1));
+  const int q = c >> 4;
+  if ((r >> 4) == q) return 16L * c + (r - 16 * q);
+  return Kd + packed_off_base(c, S) + (r - 16 * (q + 1));
 }
 
 struct GemmDesc {
@@ -109,6 +111,8 @@ struct GemmDesc {
   int pk_m = 0;
   long kflat_total = 0, kflat_diag = 0;
   int kflat_nsd = 0;
+  int kstagger = 0;        // GEMM_KFLAT: workgroup (tm, tn) starts its K walk ((tm + tn) & 7) * kstagger chunks into
+                           // its split and wraps around (see gemm_f64_kseg_lds_kernel)
 };
 
 int gemm(hipStream_t st, const GemmDesc& d);

@@ -226,6 +226,8 @@ __global__ void scatter_vec_kernel(const double* __restrict__ src, const int* __
 
 // ------------------------------------------------------------------ host drivers
 static long opt_t_batch = 0, opt_p_batch = 0;
+int opt_gemm3_ksplit = 0;    // option "gemm3_ksplit": split-K factor of GEMM3 / GEMM3' (0 = auto)
+int opt_gemm3_stagger = 0;   // option "gemm3_stagger": K-walk stagger of GEMM3' in chunks of 16 (GemmDesc::kstagger)
 void set_batch_opts(long t, long p) {
   if (t >= 0) opt_t_batch = t;
   if (p >= 0) opt_p_batch = p;
@@ -293,7 +295,7 @@ static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
   double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes) * 0.92;
-  double need = (double)b.nd * packed_total_elems(b.msz) * 8.0 + (double)pcap * mm * 8.0 + 1.0e9;
+  double need = (double)b.nd * packed_ld(b.msz) * 8.0 + (double)pcap * mm * 8.0 + 10.0e9;   // + split-K slabs
   if (need > avail) return false;
   *pcap_out = pcap;
   return true;
@@ -341,14 +343,14 @@ static int factor_w(lrn_ctx* c, LmiBlock& b, bool* ok) {
 static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   const int m = b.msz, nd = b.nd, n = c->nvar;
   const long mm = (long)m * m;
-  const long Kp = packed_total_elems(m), Kd = packed_diag_elems(m);
+  const long Kp = packed_total_elems(m), Kd = packed_diag_elems(m), Kld = packed_ld(m);
   double* Ut = c->wchol.as<double>() + mm;
   // ---- workspaces: P (batch of row-major A_k L), T (all At_k, packed)
   LRN_TRY(ensure(c, c->P, (size_t)P_cap * mm * 8));
   const void* t_before = c->T.p;
-  LRN_TRY(ensure(c, c->T, (size_t)nd * Kp * 8));            // (a fresh allocation comes back zeroed)
+  LRN_TRY(ensure(c, c->T, (size_t)nd * Kld * 8));           // (a fresh allocation comes back zeroed)
   if (c->T.p == t_before && (c->T_layout != 1 || c->T_m != m || c->T_owner != &b))
-    LRN_HIP(c, hipMemsetAsync(c->T.p, 0, (size_t)nd * Kp * 8, c->stream));   // padding rows must be zero
+    LRN_HIP(c, hipMemsetAsync(c->T.p, 0, (size_t)nd * Kld * 8, c->stream));  // padding rows must be zero
   c->T_layout = 1;
   c->T_m = m;
   c->T_owner = &b;
@@ -370,7 +372,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     GemmDesc g2;   // At = L' P, tiles i >= j, K from the tile's row origin, stored packed
     g2.A = Ut; g2.sAm = 1; g2.sAk = m; g2.bA = 0;           // op(A)[i][k] = L[k,i] = Ut[i + k*m]
     g2.B = P; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
-    g2.C = T + (long)a * Kp; g2.sCm = 1; g2.sCn = m; g2.bC = Kp;
+    g2.C = T + (long)a * Kld; g2.sCm = 1; g2.sCn = m; g2.bC = Kld;
     g2.M = g2.N = g2.K = m; g2.batch = nb;
     g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED;
     g2.pk_m = m;
@@ -401,7 +403,16 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     long tiles = 0;
     int tM = (M + TS - 1) / TS, tN = (N + TS - 1) / TS;
     for (int tn = 0; tn < tN; ++tn) tiles += std::max(0, tM - tn);
+    // split-K: short workgroups keep the co-resident workgroups of an XCD (one super-tile of the list, shared
+    // panels) close together in K, which is what lets them share the panels through L2 -- measured at C4:
+    // GEMM3' 548 / 524 / 509 / 505 ms with 8 / 16 / 32 / 64 splits.  Largest factor <= 64 that fills whole rounds
+    // of workgroup slots, leaves every split >= 1024 K-chunks and keeps the slabs within 9 GB.
     int ksplit = pick_ksplit(tiles, (int)std::min<long>(64, std::max<long>(1, Kp / BK_CHUNK / 8)));
+    for (int k = 64; k > ksplit; --k) {
+      if (Kp / BK_CHUNK / k < 1024 || (double)k * M * N * 8.0 > 9.0e9) continue;
+      if (fill_eff(tiles * k) >= 0.97) { ksplit = k; break; }
+    }
+    if (opt_gemm3_ksplit > 0) ksplit = std::min(64, opt_gemm3_ksplit);
     int nsd = ksplit;
     if (Kd < Kp) {
       if (ksplit < 2) ksplit = 2;
@@ -410,12 +421,13 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     }
     LRN_TRY(ensure(c, c->slabs, (size_t)ksplit * M * N * 8));
     GemmDesc g3;
-    g3.A = T + (long)s0 * Kp; g3.sAm = Kp; g3.sAk = 1;
-    g3.B = T + (long)s0 * Kp; g3.sBk = 1; g3.sBn = Kp;
+    g3.A = T + (long)s0 * Kld; g3.sAm = Kld; g3.sAk = 1;
+    g3.B = T + (long)s0 * Kld; g3.sBk = 1; g3.sBn = Kld;
     g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
     g3.M = M; g3.N = N;
     g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT;
     g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = nsd;
+    g3.kstagger = opt_gemm3_stagger;
     g3.ksplit = ksplit; g3.sCs = (long)M * N;
     LRN_TRY(gemm(c->stream, g3));
     toc(c, "gemm3");
@@ -572,6 +584,11 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
       int tM = (M + TS - 1) / TS, tN = (N + TS - 1) / TS;
       for (int tn = 0; tn < tN; ++tn) tiles += std::max(0, tM - tn);
       int ksplit = pick_ksplit(tiles, std::min(64, std::max(1, m / 8)));
+      for (int k = std::min(64, m / 8); k > ksplit; --k) {      // prefer short workgroups (see GEMM3' above)
+        if ((long)m * m / 2 / BK_CHUNK / k < 1024 || (double)k * M * N * 8.0 > 9.0e9) continue;
+        if (fill_eff(tiles * k) >= 0.97) { ksplit = k; break; }
+      }
+      if (opt_gemm3_ksplit > 0) ksplit = std::min(64, opt_gemm3_ksplit);
       size_t slab_bytes = (size_t)ksplit * M * N * 8;
       LRN_TRY(ensure(c, c->slabs, slab_bytes));
       GemmDesc g3;
