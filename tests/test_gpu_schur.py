@@ -429,3 +429,26 @@ def test_via_l_path_sharded_three_ranks(dev):
     assert relerr(H2, Hfull) < 1e-13
     A = np.stack([dev.get_constraint(0, k) for k in range(0, nvar, 60)])
     assert relerr(H2[::60, ::60], _brute_H(A, W)) < 1e-13
+
+
+@pytest.mark.parametrize("ksplit,stagger", [(1, 0), (3, 0), (7, 5), (64, 1000)])
+def test_chol_path_split_and_stagger_knobs(dev, ksplit, stagger):
+    """GEMM3' under non-default split-K factors and K-walk staggers (wrap-around inside a split, more stagger
+    than chunks, a single split): same matrix as the default to round-off."""
+    msz, nvar = 270, 150
+    dev.synthetic_dense_model(msz, nvar, 21)
+    W, G = _spd(msz, 22)
+    dev.set_scaling(0, W, G)
+    dev.reset_timing()
+    H0 = dev.schur_assemble(0, want_H=True)
+    assert dev.count("schur_chol") == 1
+    try:
+        dev.set_option("gemm3_ksplit", ksplit)
+        dev.set_option("gemm3_stagger", stagger)
+        H1 = dev.schur_assemble(0, want_H=True)
+    finally:
+        dev.set_option("gemm3_ksplit", 0)
+        dev.set_option("gemm3_stagger", 0)
+    assert relerr(H1, H0) < 1e-14
+    A = np.stack([dev.get_constraint(0, k) for k in range(0, nvar, 30)])
+    assert relerr(H1[::30, ::30], _brute_H(A, W)) < 1e-13
