@@ -201,6 +201,8 @@ def main():
 
     if os.environ.get("LRN_GEMM3_KSPLIT"):                     # experiment knob (split-K factor of GEMM3')
         dev.set_option("gemm3_ksplit", int(os.environ["LRN_GEMM3_KSPLIT"]))
+    if os.environ.get("LRN_P_BATCH"):                          # experiment knob: constraint matrices per GEMM1'/2' launch
+        dev.set_option("p_batch", int(os.environ["LRN_P_BATCH"]))
     if os.environ.get("LRN_GEMM3_STAGGER"):
         dev.set_option("gemm3_stagger", int(os.environ["LRN_GEMM3_STAGGER"]))
     dev.set_option("profile", 0)

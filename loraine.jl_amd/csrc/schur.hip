@@ -285,12 +285,20 @@ static long pick_p_batch(int m, long limit) {
 // are replicated: the path is chosen for world <= 2 only (1.1 msz^3 * nd  vs  3 msz^3 * nd / world).
 int opt_schur_chol = -1;     // option "schur_chol": -1 auto, 0 never, 1 whenever the data allows it
 
+// Matrices per launch of the triangular-K products: their workgroups differ in length, so every launch ends with a
+// drain of about half the longest workgroup -- fewer, larger launches (measured at C4: GEMM1'+GEMM2' 569 / 555 /
+// 547 / 545 ms per step with 64 / 128 / 256 / 500 matrices per launch); up to 8.6 GB of P workspace.
+static long tri_p_batch(int m) {
+  long p = (long)(8.6e9 / ((double)m * m * 8.0));
+  return std::max<long>(16, std::min<long>(256, p));
+}
+
 static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
   if (opt_schur_chol == 0) return false;
   if (b.npos_nz != b.nd || b.nd < 2 || b.msz < 2) return false;   // sparse partners gather from T_k = W A_k W itself
   if (opt_schur_chol < 0 && (1.1 * c->world >= 3.0 || b.msz < 256)) return false;
   const long mm = (long)b.msz * b.msz;
-  long pcap = opt_p_batch > 0 ? opt_p_batch : 64;
+  long pcap = opt_p_batch > 0 ? opt_p_batch : tri_p_batch(b.msz);
   if (pcap > b.nd) pcap = b.nd;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
@@ -466,7 +474,7 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   if (b.t_cap == 0 || b.p_cap == 0) {
     size_t free_b = 0, total_b = 0;
     LRN_HIP(c, hipMemGetInfo(&free_b, &total_b));
-    long pcap = opt_p_batch > 0 ? opt_p_batch : pick_p_batch(m, nd);
+    long pcap = opt_p_batch > 0 ? opt_p_batch : (via_l ? tri_p_batch(m) : pick_p_batch(m, nd));
     if (pcap > nd) pcap = nd;
     // memory that is free now plus what the shared workspaces already hold
     double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes + (double)c->P2.bytes) * 0.80 -
