@@ -92,3 +92,43 @@ def test_large_truss_problems(name, expected, iters):
     assert o.objective_value() == pytest.approx(expected, rel=2e-7)
     assert abs(o.solver.iter - iters) <= 1
     print(f"{name}: {o.solver.iter} iterations, {o.solver.tottime:.2f} s")
+
+
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("name,opt,chol", [("theta1", 23.0, 1), ("control1", 17.78463, 1), ("maxG11", 629.1648, 1),
+                                           ("theta1", 23.0, 2), ("control1", 17.78463, 2)])
+def test_whole_solves_through_the_cholesky_factor_paths(name, opt, chol, resident):
+    """Every non-empty constraint matrix stored dense and the Schur matrix assembled through the Cholesky factor of
+    W on every iteration (chol=1: <L'A_iL, L'A_jL>; chol=2: T_k = L (L'A_kL) L'), down to eDIMACS = 1e-7 where W is at
+    its worst conditioning: same optimum, same iteration count (+-1) as the default paths."""
+    from loraine_jl_amd.optimizer import Optimizer
+    import loraine_jl_amd
+    path = os.path.join(GOLD, f"{name}.dat-s")
+
+    def run(**extra):
+        o = Optimizer(resident=resident)
+        o.set_silent(True)
+        o.set_attribute("kit", 0)
+        for k, v in extra.items():
+            o.set_attribute(k, v)
+        o.read_from_file(path)
+        o.optimize()
+        return o
+
+    base = run()
+    d = loraine_jl_amd.Device(0)
+    d.set_option("dense_threshold", 1)
+    d.set_option("schur_chol", chol)
+    try:
+        o = run(datasparsity=0)                 # every constraint takes branch 1 (makeBBBB.jl:81) -> the dense path
+        used = sum(t.get("schur_chol" if chol == 1 else "schur_via_l", 0) for t in o.solver.trace)
+        fails = sum(t.get("wchol_fail", 0) for t in o.solver.trace)
+    finally:
+        d.set_option("dense_threshold", -1)
+        d.set_option("schur_chol", -1)
+        d.close()
+    assert o.termination_status() == "OPTIMAL" and base.termination_status() == "OPTIMAL"
+    assert o.objective_value() == pytest.approx(opt, rel=1e-6)
+    assert o.objective_value() == pytest.approx(base.objective_value(), rel=1e-7)
+    assert abs(o.solver.iter - base.solver.iter) <= 1
+    assert used > 0 and used + fails >= o.solver.iter      # the path under test was taken (or fell back, counted)
