@@ -180,6 +180,10 @@ int lrn_get_timing(lrn_ctx* ctx, const char* key, double* ms);
 int64_t lrn_get_count(lrn_ctx* ctx, const char* key);
 /* FP64 MFMA issue-rate probe (TFLOP/s of a register-only v_mfma_f64_16x16x4_f64 loop) */
 int lrn_mfma_f64_peak(lrn_ctx* ctx, double* tflops);
+/* placement probe: launches a (nx, 1, nz) grid of 256-thread workgroups and writes, for workgroup
+ * (x, z), the XCC (XCD) id the hardware ran it on (HW_REG_XCC_ID) to out[x + nx*z] (host or device int32);
+ * with hold_us > 0 every workgroup spins that long so that a whole wave of workgroups is resident at once */
+int lrn_xcc_probe(lrn_ctx* ctx, int nx, int nz, int hold_us, int32_t* out);
 /* streaming-copy probe: achieved HBM GB/s of a 16 B/lane device copy of `bytes` */
 int lrn_hbm_copy_peak(lrn_ctx* ctx, int64_t bytes, double* gbps);
 

@@ -69,6 +69,7 @@ SIGNATURES = {
     "lrn_get_count": (C.c_int64, [c_ctx, C.c_char_p]),
     "lrn_mfma_f64_peak": (C.c_int, [c_ctx, PD]),
     "lrn_hbm_copy_peak": (C.c_int, [c_ctx, C.c_int64, PD]),
+    "lrn_xcc_probe": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "lrn_dbg_gemm": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
                                C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "lrn_dbg_mfma_probe": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -251,6 +251,27 @@ int lrn_mfma_f64_peak(lrn_ctx* c, double* tflops) {
   return mfma_f64_peak(c->stream, tflops);
 }
 
+__global__ __launch_bounds__(256) void xcc_probe_kernel(int* __restrict__ out, long hold_ticks) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (hold_ticks > 0) {
+    long t0 = wall_clock64();
+    while (wall_clock64() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(8);
+  }
+  if (threadIdx.x == 0) out[blockIdx.x + (long)gridDim.x * blockIdx.z] = (int)(xcc & 0xf);
+}
+
+int lrn_xcc_probe(lrn_ctx* c, int nx, int nz, int hold_us, int32_t* out) {
+  if (!c || !out || nx <= 0 || nz <= 0 || nz > 65535 || hold_us < 0 || hold_us > 100000) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  DBuf d;
+  LRN_TRY(ensure(c, d, (size_t)nx * nz * 4, true));
+  hipLaunchKernelGGL(xcc_probe_kernel, dim3(nx, 1, nz), dim3(256), 0, c->stream, d.as<int>(), (long)hold_us * 100);
+  int rc = copy_out(c, out, d.p, (size_t)nx * nz * 4);      // wall_clock64 ticks at 100 MHz
+  release(d);
+  return rc;
+}
+
 __global__ void copy16_kernel(const double2* __restrict__ src, double2* __restrict__ dst, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
 }

@@ -423,6 +423,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   // lock-step -- all MFMA-bound at the same rate -- and would ask L2 for the same line within the miss latency
   // of the first request; starting each one ((tm + tn) & 7) * kstagger chunks into the split (a Latin square:
   // distinct along a row and along a column of the super-tile) and wrapping around spreads them in time.
+  // Measured at C4: the L2 hit rate FALLS (11 % -> 4 %) and the kernel slows by 3-6 %; delaying the workgroups by
+  // fractions of a K-step instead (s_sleep at the start) changes nothing.  Off by default, kept as a knob.
   const int seg0 = segc;
   int left = segcend - segc;
   if (FLAT && d.kstagger > 0 && left > 0) segc = seg0 + (int)(((long)((tm + tn) & 7) * d.kstagger) % left);

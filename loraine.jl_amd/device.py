@@ -217,6 +217,13 @@ class Device:
         self._chk(self.lib.lrn_mfma_f64_peak(self.h, C.byref(v)), "lrn_mfma_f64_peak")
         return v.value
 
+    def xcc_probe(self, nx, nz=1, hold_us=0):
+        """XCC (XCD) id every workgroup of an (nx, 1, nz) grid ran on, as an (nz, nx) int32 array."""
+        out = np.zeros((nz, nx), dtype=np.int32)
+        self._chk(self.lib.lrn_xcc_probe(self.h, int(nx), int(nz), int(hold_us), out.ctypes.data_as(C.c_void_p)),
+                  "lrn_xcc_probe")
+        return out
+
     def hbm_copy_peak(self, nbytes=1 << 30):
         v = C.c_double(0.0)
         self._chk(self.lib.lrn_hbm_copy_peak(self.h, int(nbytes), C.byref(v)), "lrn_hbm_copy_peak")
