@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
           if (pk) {                               // 16x16 blocks on and below the diagonal only
-            if ((n >> 4) >= (m >> 4)) Cg[packed_lower_offset(n, m, pkS, pkKd)] = v;
+            if ((n >> 4) >= (m >> 4)) {
+              const long o = packed_lower_offset(n, m, pkS, pkKd);
+              Cg[(o >> 4) * d.pk_cstride + (o & 15)] = v;
+            }
             continue;
           }
           double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
@@ -356,7 +359,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
           if (pk) {                               // 16x16 blocks on and below the diagonal only
-            if ((n >> 4) >= (m >> 4)) Cg[packed_lower_offset(n, m, pkS, pkKd)] = v;
+            if ((n >> 4) >= (m >> 4)) {
+              const long o = packed_lower_offset(n, m, pkS, pkKd);
+              Cg[(o >> 4) * d.pk_cstride + (o & 15)] = v;
+            }
             continue;
           }
           double* c = Cg + (long)m * d.sCm + (long)n * d.sCn;
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   int segc = p.kcols[ks], segcend = p.kcols[ks + 1];
   int segr = FLAT ? 0 : (segc / 128) * 128;
   const int ld = d.kseg_ld;
-  auto chunk_base = [&]() -> long { return FLAT ? (long)segc * BK : (long)segc * ld + segr; };
+  auto chunk_base = [&]() -> long { return FLAT ? (long)segc * d.kflat_cstride : (long)segc * ld + segr; };
   // FLAT: chunks of this split not yet issued.  Workgroups that share a panel (same tm or same tn) run in
   // lock-step -- all MFMA-bound at the same rate -- and would ask L2 for the same line within the miss latency
   // of the first request; starting each one ((tm + tn) & 7) * kstagger chunks into the split (a Latin square:
@@ -605,7 +611,7 @@ int gemm(hipStream_t st, const GemmDesc& din) {
     // chunk (16 doubles) boundaries per split: kflat_nsd splits over the diagonal region, the rest over
     // the strictly-lower region (the caller weights their slabs by 2)
     if (d.kflat_total <= 0 || d.kflat_diag <= 0 || d.kflat_diag > d.kflat_total || d.kflat_nsd < 1 ||
-        d.kflat_nsd > d.ksplit || !kseg_lds_path_ok(d))
+        d.kflat_nsd > d.ksplit || d.kflat_cstride < 16 || (d.kflat_cstride & 1) || !kseg_lds_path_ok(d))
       return LRN_ERR_ARG;
     if ((d.kflat_nsd == d.ksplit) != (d.kflat_diag == d.kflat_total)) return LRN_ERR_ARG;
     d.K = (int)(d.kflat_total > 0x7fffffff ? 0x7fffffff : d.kflat_total);

@@ -78,12 +78,6 @@ __host__ __device__ inline long packed_off_base(int c, int S) {
   return 16L * (q * S - 8L * q * (q + 1)) + (long)(c - 16 * q) * (S - 16 * (q + 1));
 }
 __host__ __device__ inline long packed_total_elems(int m) { return packed_diag_elems(m) + packed_off_base(m, packed_S(m)); }
-// row stride of an array of packed matrices: Kp padded to an ODD number of 128-byte lines (rows of a panel then
-// start in different 256-byte phases; measured at C4: no effect on the L2 hit rate or the time, kept as hygiene)
-__host__ __device__ inline long packed_ld(int m) {
-  const long kp = packed_total_elems(m);
-  return ((kp >> 4) & 1) ? kp : kp + 16;
-}
 // offset of element (r, c), r / 16 >= c / 16
 __host__ __device__ inline long packed_lower_offset(int r, int c, int S, long Kd) {
   const int q = c >> 4;
@@ -109,6 +103,12 @@ struct GemmDesc {
   int kseg_ld = 0, kseg_cols = 0;
   // GEMM_C_PACKED: side of the packed matrix.  GEMM_KFLAT: K = kflat_total, diagonal region and its splits
   int pk_m = 0;
+  // Chunk-major storage of an ARRAY of packed matrices: chunk q (16 doubles) of matrix k lives at
+  // q * pk_cstride + 16 k + (0..15), so the same chunk of 128 consecutive matrices -- one operand panel of the
+  // rank-k update per K-step -- is one contiguous 16 KB block (one DRAM page / TLB entry instead of 128 rows 16 MB
+  // apart).  GEMM_C_PACKED: bC = 16; GEMM_KFLAT: sAm = sBn = 16, chunks kflat_cstride apart.  16 = one matrix alone.
+  long pk_cstride = 16;
+  long kflat_cstride = 16;
   long kflat_total = 0, kflat_diag = 0;
   int kflat_nsd = 0;
   int kstagger = 0;        // GEMM_KFLAT: workgroup (tm, tn) starts its K walk ((tm + tn) & 7) * kstagger chunks into

@@ -303,7 +303,7 @@ static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
   double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes) * 0.92;
-  double need = (double)b.nd * packed_ld(b.msz) * 8.0 + (double)pcap * mm * 8.0 + 10.0e9;   // + split-K slabs
+  double need = (double)b.nd * packed_total_elems(b.msz) * 8.0 + (double)pcap * mm * 8.0 + 10.0e9;   // + split-K slabs
   if (need > avail) return false;
   *pcap_out = pcap;
   return true;
@@ -351,14 +351,16 @@ static int factor_w(lrn_ctx* c, LmiBlock& b, bool* ok) {
 static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   const int m = b.msz, nd = b.nd, n = c->nvar;
   const long mm = (long)m * m;
-  const long Kp = packed_total_elems(m), Kd = packed_diag_elems(m), Kld = packed_ld(m);
+  const long Kp = packed_total_elems(m), Kd = packed_diag_elems(m);
+  const long cstride = 16L * nd;              // chunk-major: chunk q of At_k at q * cstride + 16 k
+  const size_t t_bytes = (size_t)(Kp / 16) * cstride * 8;
   double* Ut = c->wchol.as<double>() + mm;
   // ---- workspaces: P (batch of row-major A_k L), T (all At_k, packed)
   LRN_TRY(ensure(c, c->P, (size_t)P_cap * mm * 8));
   const void* t_before = c->T.p;
-  LRN_TRY(ensure(c, c->T, (size_t)nd * Kld * 8));           // (a fresh allocation comes back zeroed)
+  LRN_TRY(ensure(c, c->T, t_bytes));                        // (a fresh allocation comes back zeroed)
   if (c->T.p == t_before && (c->T_layout != 1 || c->T_m != m || c->T_owner != &b))
-    LRN_HIP(c, hipMemsetAsync(c->T.p, 0, (size_t)nd * Kld * 8, c->stream));  // padding rows must be zero
+    LRN_HIP(c, hipMemsetAsync(c->T.p, 0, t_bytes, c->stream));               // padding rows must be zero
   c->T_layout = 1;
   c->T_m = m;
   c->T_owner = &b;
@@ -380,7 +382,8 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     GemmDesc g2;   // At = L' P, tiles i >= j, K from the tile's row origin, stored packed
     g2.A = Ut; g2.sAm = 1; g2.sAk = m; g2.bA = 0;           // op(A)[i][k] = L[k,i] = Ut[i + k*m]
     g2.B = P; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
-    g2.C = T + (long)a * Kld; g2.sCm = 1; g2.sCn = m; g2.bC = Kld;
+    g2.C = T + (long)a * 16; g2.sCm = 1; g2.sCn = m; g2.bC = 16;
+    g2.pk_cstride = cstride;
     g2.M = g2.N = g2.K = m; g2.batch = nb;
     g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED;
     g2.pk_m = m;
@@ -429,8 +432,9 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     }
     LRN_TRY(ensure(c, c->slabs, (size_t)ksplit * M * N * 8));
     GemmDesc g3;
-    g3.A = T + (long)s0 * Kld; g3.sAm = Kld; g3.sAk = 1;
-    g3.B = T + (long)s0 * Kld; g3.sBk = 1; g3.sBn = Kld;
+    g3.A = T + (long)s0 * 16; g3.sAm = 16; g3.sAk = 1;
+    g3.B = T + (long)s0 * 16; g3.sBk = 1; g3.sBn = 16;
+    g3.kflat_cstride = cstride;
     g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
     g3.M = M; g3.N = N;
     g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT;
