@@ -7,9 +7,9 @@ One "step" = one pass of the hot path over one iterate: assemble H (GEMM1/2/3 on
 MFMA; on one or two ranks through the Cholesky factor of W), factor it
 (blocked Cholesky) and run the predictor and corrector solves.  Inputs
 (constraint data, NT scaling W, right-hand sides) are resident in HBM when the timed region
-starts.  N > 1: one process per GPU (torchrun), Schur column blocks sharded block-cyclically,
-RCCL all-gather of the owned blocks before the factorisation; total work is fixed
-(`"scaling": "strong"`).
+starts.  N > 1: one process per GPU (torchrun); the ranks split the columns of the matrix variable
+(every GEMM of the assembly shards) and one RCCL all-reduce adds their partial Schur matrices before
+the replicated factorisation; total work is fixed (`"scaling": "strong"`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--msz 2000] [--nvar 4000]
 """
@@ -173,12 +173,25 @@ def main():
         dev.set_shard(rank, world)
         shard = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
         gathered = torch.zeros(dev.shard_doubles() * world, dtype=torch.float64, device="cuda")
+        hfull = torch.zeros(nvar * nvar, dtype=torch.float64, device="cuda")
     from loraine_jl_amd._capi import ptr
     lib = dev.lib
 
     def step():
         dev.schur_assemble(0)                                   # makeBBBBs on the owned columns
-        if sharded:
+        if sharded and dev.schur_is_partial_sum():
+            # Cholesky path: the ranks split the columns of the matrix variable, each holds a partial sum of H
+            dev.schur_export_full(hfull)
+            if backend == "nccl":
+                dist.all_reduce(hfull)                          # RCCL over xGMI, nvar^2 doubles
+                torch.cuda.current_stream().synchronize()
+            else:
+                h_host = hfull.cpu()
+                dist.all_reduce(h_host)
+                hfull.copy_(h_host)
+                torch.cuda.synchronize()
+            dev.schur_import_full(hfull)
+        elif sharded:
             dev.schur_export_shard(shard)
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered, shard)    # RCCL over xGMI
@@ -247,12 +260,18 @@ def main():
             # Schur entry; units = lower-triangle entries of the owned columns (position space)
             entries = float(sum(nvar - int(j) for j in own))
             alg_flops_launch = entries * msz * (msz + 1.0) / launches_per_step
+            if chol_path and world > 1:
+                # every rank forms ALL entries over ITS columns of the matrix variable: its share of the packed
+                # length (timed as gemm3 over all its launches)
+                alg_flops_launch = (nvar * (nvar + 1.0) / 2.0) * msz * (msz + 1.0) * dev.timing("gemm3_share") / launches_per_step
             kname = ("gemm_f64_kseg_lds_kernel<true> GEMM3' H[j,i] = <L'A_jL, L'A_iL> (packed lower tiles, split-K)"
                      if chol_path else "gemm_f64_kseg_lds_kernel<false> GEMM3 H[j,i] = <A_j, W A_i W> (lower tiles, split-K)")
             kpat = "gemm_f64_kseg_lds_kernel<true>" if chol_path else "gemm_f64_kseg_lds_kernel<false>"
         elif dom == "gemm1":
             units_per_launch = (nvar if chol_path else nown) / launches_per_step      # constraint matrices per launch
             alg_flops_launch = (2.0 / 3.0 if chol_path else (1.0 if via_l else 2.0)) * msz ** 3 * units_per_launch
+            if chol_path:
+                alg_flops_launch *= dev.timing("gemm1_share")       # this rank's columns of the matrix variable
             kname = ("gemm_f64_lds_kernel<false> GEMM1' P_k = A_k L (lower tiles, triangular K)" if chol_path
                      else ("gemm_f64_lds_kernel P_k = A_k L and At_k = L'P_k (timed together; lower tiles, triangular K)" if via_l
                            else "gemm_f64_lds_kernel<false> GEMM1 P_k = A_k W (batched, direct-to-LDS staging)"))
@@ -260,6 +279,8 @@ def main():
         else:
             units_per_launch = (nvar if chol_path else nown) / launches_per_step
             alg_flops_launch = (1.0 / 3.0 if chol_path else 1.0) * msz ** 3 * units_per_launch
+            if chol_path:
+                alg_flops_launch *= dev.timing("gemm2_share")
             kname = ("gemm_f64_lds_kernel Q_k = L At_k and T_k = Q_k L' (timed together; lower tiles, triangular K)" if via_l
                      else "gemm_f64_lds_kernel<true> GEMM2 (lower tiles)")
             kpat = "gemm_f64_lds_kernel<true>"
@@ -275,7 +296,9 @@ def main():
             "config": {"workload": f"C4 synthetic dense SDP, matrix side {msz}, {nvar} constraints, kit=0 "
                                    f"(assembly + Cholesky + predictor/corrector solves)",
                        "msz": msz, "nvar": nvar, "seed": args.seed,
-                       "parallelism": "1 GPU" if world == 1 else f"Schur column blocks over {world} GPUs + RCCL all-gather"},
+                       "parallelism": "1 GPU" if world == 1 else (
+                           f"columns of the matrix variable over {world} GPUs + RCCL all-reduce of the partial Schur matrices"
+                           if chol_path else f"Schur column blocks over {world} GPUs + RCCL all-gather")},
             "algorithmic_tflops": flops_model(msz, nvar) / (ms_per_step * 1e-3) / 1e12,
             "assembly_path": ("cholesky (H_ij = <L'A_iL, L'A_jL>, W = LL')" if chol_path
                               else ("T_k = L (L'A_kL) L', W = LL'" if via_l else "T_k = W A_k W")),

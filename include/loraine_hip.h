@@ -103,6 +103,14 @@ int lrn_schur_solve(lrn_ctx* ctx, const double* h, double* dely);
 int64_t lrn_schur_shard_doubles(lrn_ctx* ctx);
 int lrn_schur_export_shard(lrn_ctx* ctx, double* buf);
 int lrn_schur_import_all(lrn_ctx* ctx, const double* buf_all);
+/* multi-GPU, dense data through the Cholesky factor of W: the ranks split the COLUMNS of the matrix variable, so
+ * after lrn_schur_assemble every rank holds a partial SUM of the whole Schur matrix (lrn_schur_is_partial_sum = 1)
+ * and the exchange is one all-reduce of nvar^2 doubles: export_full -> all-reduce(sum) -> import_full
+ * (buffers host or device, position space, lower triangle authoritative).  When it returns 0 the owned column
+ * blocks are exchanged with export_shard / all-gather / import_all as above. */
+int lrn_schur_is_partial_sum(lrn_ctx* ctx);
+int lrn_schur_export_full(lrn_ctx* ctx, double* buf);
+int lrn_schur_import_full(lrn_ctx* ctx, const double* buf);
 
 /* ---- right-hand sides: makeRHS (src/makeBBBB.jl:221-228), corrector :186 --------------- */
 /* h = Rp + sum AA*vec(W (Rd+S) W) ; Rd_plus_S: msz x msz per block, concatenated */

@@ -44,6 +44,9 @@ SIGNATURES = {
     "lrn_schur_shard_doubles": (C.c_int64, [c_ctx]),
     "lrn_schur_export_shard": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_schur_import_all": (C.c_int, [c_ctx, C.c_void_p]),
+    "lrn_schur_is_partial_sum": (C.c_int, [c_ctx]),
+    "lrn_schur_export_full": (C.c_int, [c_ctx, C.c_void_p]),
+    "lrn_schur_import_full": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_make_rhs": (C.c_int, [c_ctx, C.c_void_p, PPD, C.c_void_p]),
     "lrn_matvec": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     "lrn_matvec_partial": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),

@@ -185,9 +185,32 @@ int64_t lrn_schur_shard_doubles(lrn_ctx* c) {
   return (int64_t)bpr * c->shard_bs * c->nvar;
 }
 
+int lrn_schur_is_partial_sum(lrn_ctx* c) { return c && c->have_H && c->H_partial ? 1 : 0; }
+
+int lrn_schur_export_full(lrn_ctx* c, double* buf) {
+  if (!c || !buf) return LRN_ERR_ARG;
+  if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  LRN_HIP(c, hipSetDevice(c->device));
+  return copy_out(c, buf, c->H.p, (size_t)c->nvar * c->nvar * 8);
+}
+
+int lrn_schur_import_full(lrn_ctx* c, const double* buf) {
+  if (!c || !buf) return LRN_ERR_ARG;
+  if (c->nvar <= 0 || !c->H.p) return set_error(c, LRN_ERR_STATE, "no model / Schur matrix");
+  LRN_HIP(c, hipSetDevice(c->device));
+  LRN_TRY(copy_in(c, c->H.p, buf, (size_t)c->nvar * c->nvar * 8));
+  c->have_H = true;
+  c->H_partial = false;
+  c->H_shifted = false;
+  c->have_L = false;
+  return LRN_OK;
+}
+
 int lrn_schur_export_shard(lrn_ctx* c, double* buf) {
   if (!c || !buf) return LRN_ERR_ARG;
   if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  if (c->H_partial)
+    return set_error(c, LRN_ERR_STATE, "H holds a partial sum: exchange it with lrn_schur_export_full + all-reduce");
   if (!is_device_ptr(buf)) return set_error(c, LRN_ERR_ARG, "shard buffer must be device memory");
   int nblk, bpr;
   shard_geom(c, &nblk, &bpr);

@@ -81,6 +81,7 @@ struct lrn_ctx {
   lrn::DBuf hdiag;            // diag(H) before the factorisation (pivot boosting)
   bool have_H = false, have_L = false;
   bool H_shifted = false;     // lrn_schur_add_diag since the last assembly: strict Cholesky only
+  bool H_partial = false;     // world > 1, Cholesky path: H is this rank's partial SUM (exchange = all-reduce)
   // assembly workspaces
   lrn::DBuf P, P2, T, slabs, Hd, BG;
   lrn::DBuf m0, m1, m2, cgbuf;   // msz^2 work matrices (mat-vec / rhs), PCG vectors

@@ -32,7 +32,8 @@ struct GemmParams {
   GemmDesc d;
   int tilesM, tilesN;
   int kchunk;                    // K elements per split (multiple of BK), non-KSEG
-  int kcols[MAX_KSPLIT + 1];     // KSEG: column range per split
+  int kcols[MAX_KSPLIT + 1];     // KSEG: column range per split; KFLAT: first chunk of split s
+  int kcols2[MAX_KSPLIT + 1];    // KFLAT: end chunk of split s
   const int2* tile_list;         // (tm, tn) per workgroup, super-tile order
 };
 
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
           if (sq) v = v * v;
           if (pk) {                               // 16x16 blocks on and below the diagonal only
             if ((n >> 4) >= (m >> 4)) {
-              const long o = packed_lower_offset(n, m, pkS, pkKd);
+              const long o = packed_lower_offset(n + d.pk_off, m + d.pk_off, pkS, pkKd);
               Cg[(o >> 4) * d.pk_cstride + (o & 15)] = v;
             }
             continue;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
           if (sq) v = v * v;
           if (pk) {                               // 16x16 blocks on and below the diagonal only
             if ((n >> 4) >= (m >> 4)) {
-              const long o = packed_lower_offset(n, m, pkS, pkKd);
+              const long o = packed_lower_offset(n + d.pk_off, m + d.pk_off, pkS, pkKd);
               Cg[(o >> 4) * d.pk_cstride + (o & 15)] = v;
             }
             continue;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
     pa[j] = Ag + (long)ra * d.sAm + 2 * src_pair;
     pb[j] = Bg + (long)rb * d.sBn + 2 * src_pair;
   }
-  int segc = p.kcols[ks], segcend = p.kcols[ks + 1];
+  int segc = p.kcols[ks], segcend = FLAT ? p.kcols2[ks] : p.kcols[ks + 1];
   int segr = FLAT ? 0 : (segc / 128) * 128;
   const int ld = d.kseg_ld;
   auto chunk_base = [&]() -> long { return FLAT ? (long)segc * d.kflat_cstride : (long)segc * ld + segr; };
@@ -598,7 +599,12 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   const bool kseg = (d.flags & GEMM_KSEG_TRI) || kflat;
   const bool kfrom = d.flags & (GEMM_KFROM_N | GEMM_KFROM_M | GEMM_KTO_N | GEMM_KTO_M);   // triangular K ranges
   if ((d.flags & GEMM_C_MIRROR) && (d.M != d.N || !tri || d.beta != 0.0)) return LRN_ERR_ARG;
-  if (kfrom && (d.ksplit != 1 || d.M != d.N || d.M != d.K || kseg)) return LRN_ERR_ARG;
+  // triangular K ranges: the operand that is triangular spans K (a trailing sub-block may be narrower in the other
+  // dimension: columns [c0, c1) of a product with the trailing block of the factor)
+  if (kfrom && (d.ksplit != 1 || kseg)) return LRN_ERR_ARG;
+  if ((d.flags & (GEMM_KFROM_N | GEMM_KTO_N)) && d.N > d.K) return LRN_ERR_ARG;
+  if ((d.flags & (GEMM_KFROM_M | GEMM_KTO_M)) && d.M > d.K) return LRN_ERR_ARG;
+  if ((d.flags & GEMM_C_PACKED) && (d.pk_off & 127)) return LRN_ERR_ARG;
   if ((d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)) return LRN_ERR_ARG;
   // tile choice: 128x128 unless the problem is too small to fill the chip with it
   long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit;
@@ -613,12 +619,24 @@ int gemm(hipStream_t st, const GemmDesc& din) {
     if (d.kflat_total <= 0 || d.kflat_diag <= 0 || d.kflat_diag > d.kflat_total || d.kflat_nsd < 1 ||
         d.kflat_nsd > d.ksplit || d.kflat_cstride < 16 || (d.kflat_cstride & 1) || !kseg_lds_path_ok(d))
       return LRN_ERR_ARG;
-    if ((d.kflat_nsd == d.ksplit) != (d.kflat_diag == d.kflat_total)) return LRN_ERR_ARG;
-    d.K = (int)(d.kflat_total > 0x7fffffff ? 0x7fffffff : d.kflat_total);
+      d.K = (int)(d.kflat_total > 0x7fffffff ? 0x7fffffff : d.kflat_total);
     const long cd = d.kflat_diag / BK, ct = d.kflat_total / BK;
-    const int nsd = d.kflat_nsd, nso = d.ksplit - nsd;
-    for (int s = 0; s <= nsd; ++s) p.kcols[s] = (int)(cd * s / nsd);
-    for (int s = 1; s <= nso; ++s) p.kcols[nsd + s] = (int)(cd + (ct - cd) * s / nso);
+    // split s walks the chunks [kcols[s], kcols2[s])
+    if (d.kflat_kb && d.kflat_ke) {
+      for (int s = 0; s < d.ksplit; ++s) {
+        if (d.kflat_kb[s] < 0 || d.kflat_ke[s] < d.kflat_kb[s] || d.kflat_ke[s] > ct) return LRN_ERR_ARG;
+        p.kcols[s] = d.kflat_kb[s];
+        p.kcols2[s] = d.kflat_ke[s];
+      }
+    } else {
+      const int nsd = d.kflat_nsd, nso = d.ksplit - nsd;
+      if ((nso == 0) != (ct == cd)) return LRN_ERR_ARG;
+      for (int s = 0; s < nsd; ++s) { p.kcols[s] = (int)(cd * s / nsd); p.kcols2[s] = (int)(cd * (s + 1) / nsd); }
+      for (int s = 0; s < nso; ++s) {
+        p.kcols[nsd + s] = (int)(cd + (ct - cd) * s / nso);
+        p.kcols2[nsd + s] = (int)(cd + (ct - cd) * (s + 1) / nso);
+      }
+    }
     p.kchunk = 0;
   } else if (kseg) {
     if (d.kseg_ld <= 0 || d.kseg_cols <= 0) return LRN_ERR_ARG;

@@ -108,7 +108,13 @@ struct GemmDesc {
   // rank-k update per K-step -- is one contiguous 16 KB block (one DRAM page / TLB entry instead of 128 rows 16 MB
   // apart).  GEMM_C_PACKED: bC = 16; GEMM_KFLAT: sAm = sBn = 16, chunks kflat_cstride apart.  16 = one matrix alone.
   long pk_cstride = 16;
+  int pk_off = 0;           // GEMM_C_PACKED on a trailing sub-block: kernel indices + pk_off = indices in the packed matrix
   long kflat_cstride = 16;
+  // GEMM_KFLAT with explicit splits (multi-GPU partial sums over column ranges of the packed matrices): split s walks
+  // the chunks [kflat_kb[s], kflat_ke[s]) (host arrays of `ksplit` entries); null = kflat_nsd splits over the
+  // diagonal region and the others over the strictly-lower region of the whole matrix
+  const int* kflat_kb = nullptr;
+  const int* kflat_ke = nullptr;
   long kflat_total = 0, kflat_diag = 0;
   int kflat_nsd = 0;
   int kstagger = 0;        // GEMM_KFLAT: workgroup (tm, tn) starts its K walk ((tm + tn) & 7) * kstagger chunks into

@@ -281,9 +281,68 @@ static long pick_p_batch(int m, long limit) {
 //        GEMM3'  H[j,i] = <At_j, At_i>   (nvar^2 msz^2 / 2, as before).
 // The perturbation is that of a backward-stable Cholesky of W (||L L' - W|| <= c msz eps ||W||), the level W
 // itself is known to; when the factorisation of W breaks down (W numerically singular late in a solve) the
-// T_k = W A_k W path below takes over.  Every rank needs every At_k, so with the column sharding the products
-// are replicated: the path is chosen for world <= 2 only (1.1 msz^3 * nd  vs  3 msz^3 * nd / world).
+// T_k = W A_k W path below takes over.  Multi-GPU: the columns of the matrix variable are dealt to the ranks
+// (col_tile_runs) -- all three GEMMs shard and the ranks' partial Schur matrices are summed by one all-reduce.
 int opt_schur_chol = -1;     // option "schur_chol": -1 auto, 0 never, 1 whenever the data allows it
+
+// out[(i) + (j)*ldo] += sum_s w[s] * slab_s[i + j*M]  (lower 128-tiles; fixed order; weights 1 / 2 are exact)
+struct SlabWeights {
+  static constexpr int MAXS = 160;
+  float w[MAXS];
+};
+__global__ void reduce_slabs_w_kernel(const double* __restrict__ slabs, long stride, int nslab, SlabWeights sw, int M,
+                                      int N, double* __restrict__ out, long ldo) {
+  long total = (long)M * N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % M), j = (int)(e / M);
+    if (i / TS < j / TS) continue;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nslab; ++k) {
+      const double v = slabs[(long)k * stride + e];
+      if (sw.w[k] == 1.0f) s1 += v; else s2 += v;
+    }
+    out[(long)i + (long)j * ldo] += s1 + 2.0 * s2;
+  }
+}
+
+// Multi-GPU split of the Cholesky path: the COLUMNS of the matrix variable.  Column c of every At_k = L' A_k L needs
+// only columns >= c of L and A_k, and <At_i, At_j> is a sum over columns -- so a rank that owns a set of 128-column
+// tiles computes those columns of every P_k and At_k and its share of every inner product: all three GEMMs shard, no
+// intermediate is exchanged, and the ranks' partial Schur matrices are added by one all-reduce (nvar^2 doubles).
+// Every rank gets one contiguous range of tiles, chosen to minimise the largest load; work of tile t per constraint:
+// GEMM1' (nt-t) tiles of K = m-128t, GEMM2' tiles (i>=t) of K = m-128i, GEMM3' nd/2 x its packed length.
+static std::vector<std::pair<int, int>> col_tile_runs(int m, int nd, int rank, int world) {
+  const int nt = (m + 127) / 128, S = packed_S(m);
+  std::vector<std::pair<int, int>> runs;
+  if (world <= 1) { runs.push_back({0, nt}); return runs; }
+  std::vector<double> cost(nt);
+  for (int t = 0; t < nt; ++t) {
+    double k1 = (double)(nt - t) * (m - 128.0 * t), k2 = 0.0;
+    for (int i = t; i < nt; ++i) k2 += m - 128.0 * i;
+    const int c0 = 128 * t, c1 = std::min(m, c0 + 128);
+    const double k3 = (double)(16 * (c1 - c0)) + (double)(packed_off_base(c1, S) - packed_off_base(c0, S));
+    cost[t] = (k1 + k2) * 32768.0 + 0.5 * (double)nd * k3 * 2.0;
+  }
+  // contiguous ranges (one run per rank: one launch per GEMM and batch) minimising the largest load:
+  // dp[p][j] = best largest load of the first j tiles over p ranks; ties keep the smallest cut
+  const int P = std::min(world, nt);
+  std::vector<double> pre(nt + 1, 0.0);
+  for (int t = 0; t < nt; ++t) pre[t + 1] = pre[t] + cost[t];
+  std::vector<std::vector<double>> dp(P + 1, std::vector<double>(nt + 1, 1e300));
+  std::vector<std::vector<int>> cut(P + 1, std::vector<int>(nt + 1, 0));
+  dp[0][0] = 0.0;
+  for (int p = 1; p <= P; ++p)
+    for (int j = p; j <= nt; ++j)
+      for (int i = p - 1; i < j; ++i) {
+        const double seg = pre[j] - pre[i];
+        const double v = dp[p - 1][i] > seg ? dp[p - 1][i] : seg;
+        if (v < dp[p][j]) { dp[p][j] = v; cut[p][j] = i; }
+      }
+  std::vector<int> lo(P), hi(P);
+  for (int p = P, j = nt; p >= 1; --p) { lo[p - 1] = cut[p][j]; hi[p - 1] = j; j = cut[p][j]; }
+  if (rank < P) runs.push_back({lo[rank], hi[rank]});
+  return runs;
+}
 
 // Matrices per launch of the triangular-K products: their workgroups differ in length, so every launch ends with a
 // drain of about half the longest workgroup -- fewer, larger launches (measured at C4: GEMM1'+GEMM2' 569 / 555 /
@@ -296,7 +355,8 @@ static long tri_p_batch(int m) {
 static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
   if (opt_schur_chol == 0) return false;
   if (b.npos_nz != b.nd || b.nd < 2 || b.msz < 2) return false;   // sparse partners gather from T_k = W A_k W itself
-  if (opt_schur_chol < 0 && (1.1 * c->world >= 3.0 || b.msz < 256)) return false;
+  if (opt_schur_chol < 0 && b.msz < 256) return false;
+  if (c->world > 1 && !c->pos_space) return false;
   const long mm = (long)b.msz * b.msz;
   long pcap = opt_p_batch > 0 ? opt_p_batch : tri_p_batch(b.msz);
   if (pcap > b.nd) pcap = b.nd;
@@ -367,30 +427,41 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   double* Ad = b.Adense.as<double>();
   double* P = c->P.as<double>();
   double* T = c->T.as<double>();
+  // ---- this rank's columns of the matrix variable (all of them on one GPU): runs of 128-column tiles
+  const std::vector<std::pair<int, int>> runs = col_tile_runs(m, nd, c->rank, c->world);
+  const int S = packed_S(m);
   for (int a = 0; a < nd; a += (int)P_cap) {
-    int nb = std::min((int)P_cap, nd - a);
-    tic(c);
-    GemmDesc g1;   // P = A_a L, row-major (P[i][j] at j + i*m), tiles i >= j, K from the tile's column origin
-    g1.A = Ad + (long)a * mm; g1.sAm = 1; g1.sAk = m; g1.bA = mm;
-    g1.B = Ut; g1.sBk = m; g1.sBn = 1; g1.bB = 0;           // op(B)[k][j] = L[k,j] = Ut[j + k*m]
-    g1.C = P; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
-    g1.M = g1.N = g1.K = m; g1.batch = nb;
-    g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N;
-    LRN_TRY(gemm(c->stream, g1));
-    toc(c, "gemm1");
-    tic(c);
-    GemmDesc g2;   // At = L' P, tiles i >= j, K from the tile's row origin, stored packed
-    g2.A = Ut; g2.sAm = 1; g2.sAk = m; g2.bA = 0;           // op(A)[i][k] = L[k,i] = Ut[i + k*m]
-    g2.B = P; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
-    g2.C = T + (long)a * 16; g2.sCm = 1; g2.sCn = m; g2.bC = 16;
-    g2.pk_cstride = cstride;
-    g2.M = g2.N = g2.K = m; g2.batch = nb;
-    g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED;
-    g2.pk_m = m;
-    LRN_TRY(gemm(c->stream, g2));
-    toc(c, "gemm2");
+    const int nb = std::min((int)P_cap, nd - a);
+    for (auto& rn : runs) {
+      // columns [c0, c1): P[c0:, c0:c1] = A[c0:, c0:] L[c0:, c0:c1] and At[c0:, c0:c1] = L[c0:, c0:]' P[c0:, c0:c1] are
+      // the same triangular products on the trailing blocks (L lower triangular: nothing above row c0 contributes)
+      const int c0 = 128 * rn.first, c1 = std::min(m, 128 * rn.second);
+      const long off = (long)c0 + (long)c0 * m;
+      tic(c);
+      GemmDesc g1;   // P = A_a L, row-major (P[i][j] at j + i*m), tiles i >= j, K from the tile's column origin
+      g1.A = Ad + (long)a * mm + off; g1.sAm = 1; g1.sAk = m; g1.bA = mm;
+      g1.B = Ut + off; g1.sBk = m; g1.sBn = 1; g1.bB = 0;     // op(B)[k][j] = L[k,j] = Ut[j + k*m]
+      g1.C = P + off; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
+      g1.M = g1.K = m - c0; g1.N = c1 - c0; g1.batch = nb;
+      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N;
+      LRN_TRY(gemm(c->stream, g1));
+      toc(c, "gemm1");
+      tic(c);
+      GemmDesc g2;   // At = L' P, tiles i >= j, K from the tile's row origin, stored packed
+      g2.A = Ut + off; g2.sAm = 1; g2.sAk = m; g2.bA = 0;     // op(A)[i][k] = L[k,i] = Ut[i + k*m]
+      g2.B = P + off; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
+      g2.C = T + (long)a * 16; g2.sCm = 1; g2.sCn = m; g2.bC = 16;
+      g2.pk_cstride = cstride;
+      g2.M = g2.K = m - c0; g2.N = c1 - c0; g2.batch = nb;
+      g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED;
+      g2.pk_m = m;
+      g2.pk_off = c0;
+      LRN_TRY(gemm(c->stream, g2));
+      toc(c, "gemm2");
+    }
   }
-  // ---- GEMM3': H[s0:nd, s0:s1] += At[s0:nd] . At[s0:s1]'  per owned column block
+  // ---- GEMM3': H (+)= sum over this rank's columns of the packed inner products -- the whole lower triangle of H,
+  // a partial sum when world > 1 (the ranks' matrices are added by one all-reduce)
   double* H = c->H.as<double>();
   double* Hd = H;
   long ldh = n;
@@ -400,58 +471,104 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     Hd = c->Hd.as<double>();
     ldh = nd;
   }
-  std::vector<std::pair<int, int>> groups;
-  if (c->world > 1) {
-    for (int s0 = 0; s0 < nd; s0 += c->shard_bs)
-      if (shard_owner(s0 / c->shard_bs, c->world) == c->rank) groups.push_back({s0, std::min(nd, s0 + c->shard_bs)});
-  } else {
-    groups.push_back({0, nd});
-  }
-  for (auto& g : groups) {
-    const int s0 = g.first, s1 = g.second;
-    tic(c);
-    const int M = nd - s0, N = s1 - s0;
+  {
+    const int M = nd, N = nd;
     long tiles = 0;
-    int tM = (M + TS - 1) / TS, tN = (N + TS - 1) / TS;
-    for (int tn = 0; tn < tN; ++tn) tiles += std::max(0, tM - tn);
-    // split-K: short workgroups keep the co-resident workgroups of an XCD (one super-tile of the list, shared
-    // panels) close together in K, which is what lets them share the panels through L2 -- measured at C4:
-    // GEMM3' 548 / 524 / 509 / 505 ms with 8 / 16 / 32 / 64 splits.  Largest factor <= 64 that fills whole rounds
-    // of workgroup slots, leaves every split >= 1024 K-chunks and keeps the slabs within 9 GB.
-    int ksplit = pick_ksplit(tiles, (int)std::min<long>(64, std::max<long>(1, Kp / BK_CHUNK / 8)));
+    const int tM = (M + TS - 1) / TS;
+    for (int tn = 0; tn < tM; ++tn) tiles += tM - tn;
+    // chunk ranges of the runs and the split-K budget (see below) divided over them by length
+    struct RunK { long d0, d1, o0, o1; int ks, nsd; };
+    std::vector<RunK> rk;
+    long chunks_all = 0;
+    for (auto& rn : runs) {
+      const int c0 = 128 * rn.first, c1 = std::min(m, 128 * rn.second);
+      RunK r{c0, c1, (Kd + packed_off_base(c0, S)) / 16, (Kd + packed_off_base(c1, S)) / 16, 0, 0};
+      chunks_all += (r.d1 - r.d0) + (r.o1 - r.o0);
+      rk.push_back(r);
+    }
+    {   // this rank's share of the three GEMMs (bench.py prices the roofline with them; 1 on one GPU)
+      const int nt = (m + 127) / 128;
+      double k1a = 0, k2a = 0, k1o = 0, k2o = 0;
+      for (int t = 0; t < nt; ++t) {
+        double k1 = (double)(nt - t) * (m - 128.0 * t), k2 = 0.0;
+        for (int i = t; i < nt; ++i) k2 += m - 128.0 * i;
+        k1a += k1; k2a += k2;
+        for (auto& rn : runs) if (t >= rn.first && t < rn.second) { k1o += k1; k2o += k2; }
+      }
+      c->timing["gemm1_share"] = k1o / k1a;
+      c->timing["gemm2_share"] = k2o / k2a;
+      c->timing["gemm3_share"] = (double)chunks_all / (double)(Kp / 16);
+    }
+    // split-K: short workgroups fill the workgroup slots evenly -- measured at C4: GEMM3' 548 / 524 / 509 / 505 ms
+    // with 8 / 16 / 32 / 64 splits.  Largest factor <= 64 that fills whole rounds of workgroup slots, leaves every
+    // split >= 1024 K-chunks and keeps the slabs within 9 GB.
+    int ksplit = pick_ksplit(tiles, (int)std::min<long>(64, std::max<long>(1, chunks_all / 8)));
     for (int k = 64; k > ksplit; --k) {
-      if (Kp / BK_CHUNK / k < 1024 || (double)k * M * N * 8.0 > 9.0e9) continue;
+      if (chunks_all / k < 256 || (double)k * M * N * 8.0 > 9.0e9) continue;
       if (fill_eff(tiles * k) >= 0.97) { ksplit = k; break; }
     }
     if (opt_gemm3_ksplit > 0) ksplit = std::min(64, opt_gemm3_ksplit);
-    int nsd = ksplit;
-    if (Kd < Kp) {
-      if (ksplit < 2) ksplit = 2;
-      nsd = (int)((double)ksplit * (double)Kd / (double)Kp + 0.5);
-      nsd = std::max(1, std::min(ksplit - 1, nsd));
+    // the splits of all runs go into ONE launch: split s walks chunks [kb[s], ke[s]) with slab weight 1 (diagonal
+    // 16-blocks) or 2 (strictly-lower blocks)
+    SlabWeights sw;
+    std::vector<int> kb, ke;
+    int budget = std::max(ksplit, 2 * (int)rk.size());
+    if (budget > 64) budget = 64;
+    for (size_t ri = 0; ri < rk.size(); ++ri) {
+      RunK& r = rk[ri];
+      const long nd_ = r.d1 - r.d0, no_ = r.o1 - r.o0;
+      r.ks = (int)std::max<long>(1, (long)((double)budget * (double)(nd_ + no_) / (double)chunks_all + 0.5));
+      r.nsd = r.ks;
+      if (no_ > 0) {
+        if (r.ks < 2) r.ks = 2;
+        r.nsd = (int)((double)r.ks * (double)nd_ / (double)(nd_ + no_) + 0.5);
+        r.nsd = std::max(1, std::min(r.ks - 1, r.nsd));
+      }
+      if ((int)kb.size() + r.ks > 64) {         // rounding pushed the total over the kernel's limit: trim this run
+        r.ks = 64 - (int)kb.size();
+        if (r.ks < (no_ > 0 ? 2 : 1)) return set_error(c, LRN_ERR_STATE, "split-K budget exceeded (%d runs)", (int)rk.size());
+        r.nsd = no_ > 0 ? std::max(1, std::min(r.ks - 1, r.nsd)) : r.ks;
+      }
+      const int nso = r.ks - r.nsd;
+      for (int i = 0; i < r.nsd; ++i) {
+        sw.w[kb.size()] = 1.0f;
+        kb.push_back((int)(r.d0 + nd_ * i / r.nsd));
+        ke.push_back((int)(r.d0 + nd_ * (i + 1) / r.nsd));
+      }
+      for (int i = 0; i < nso; ++i) {
+        sw.w[kb.size()] = 2.0f;
+        kb.push_back((int)(r.o0 + no_ * i / nso));
+        ke.push_back((int)(r.o0 + no_ * (i + 1) / nso));
+      }
     }
-    LRN_TRY(ensure(c, c->slabs, (size_t)ksplit * M * N * 8));
-    GemmDesc g3;
-    g3.A = T + (long)s0 * 16; g3.sAm = 16; g3.sAk = 1;
-    g3.B = T + (long)s0 * 16; g3.sBk = 1; g3.sBn = 16;
-    g3.kflat_cstride = cstride;
-    g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
-    g3.M = M; g3.N = N;
-    g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT;
-    g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = nsd;
-    g3.kstagger = opt_gemm3_stagger;
-    g3.ksplit = ksplit; g3.sCs = (long)M * N;
-    LRN_TRY(gemm(c->stream, g3));
-    toc(c, "gemm3");
+    const int nslab = (int)kb.size();
+    if (nslab > 0) {
+      LRN_TRY(ensure(c, c->slabs, (size_t)nslab * M * N * 8));
+      tic(c);
+      GemmDesc g3;
+      g3.A = T; g3.sAm = 16; g3.sAk = 1;
+      g3.B = T; g3.sBk = 1; g3.sBn = 16;
+      g3.kflat_cstride = cstride;
+      g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
+      g3.M = M; g3.N = N;
+      g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT;
+      g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = 1;
+      g3.kflat_kb = kb.data(); g3.kflat_ke = ke.data();
+      g3.kstagger = opt_gemm3_stagger;
+      g3.ksplit = nslab; g3.sCs = (long)M * N;
+      LRN_TRY(gemm(c->stream, g3));
+      toc(c, "gemm3");
+    }
     tic(c);
-    hipLaunchKernelGGL(reduce_slabs_tri_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,
-                       c->slabs.as<double>(), (long)M * N, ksplit, nsd, M, N, Hd + (long)s0 + (long)s0 * ldh, ldh);
+    hipLaunchKernelGGL(reduce_slabs_w_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,
+                       c->slabs.as<double>(), (long)M * N, nslab, sw, M, N, Hd, ldh);
     toc(c, "reduce3");
   }
   if (!c->pos_space)
     hipLaunchKernelGGL(scatter_add_lower_kernel, dim3(nblocks((long)nd * nd)), dim3(256), 0, c->stream, Hd, nd,
                        b.hidx.as<int>(), H, n);
   c->counts["schur_chol"] += 1;
+  if (c->world > 1) c->H_partial = true;      // H holds this rank's partial sum: all-reduce, not all-gather
   return LRN_OK;
 }
 
@@ -707,6 +824,7 @@ int schur_assemble(lrn_ctx* c, int mode) {
     (void)hipEventRecord(a0, c->stream);
   }
   LRN_HIP(c, hipMemsetAsync(c->H.p, 0, (size_t)n * n * 8, c->stream));
+  c->H_partial = false;
   for (auto& b : c->lmi) {
     if (mode == -1) {
       LRN_TRY(assemble_rank1(c, b));

@@ -171,6 +171,17 @@ class Device:
     def shard_doubles(self):
         return int(self.lib.lrn_schur_shard_doubles(self.h))
 
+    def schur_is_partial_sum(self):
+        """True when the last assembly left this rank's partial SUM of the whole Schur matrix (dense data through
+        the Cholesky factor, world > 1): the exchange is then an all-reduce of `schur_export_full`."""
+        return bool(self.lib.lrn_schur_is_partial_sum(self.h))
+
+    def schur_export_full(self, buf):
+        self._chk(self.lib.lrn_schur_export_full(self.h, ptr(buf)), "lrn_schur_export_full")
+
+    def schur_import_full(self, buf):
+        self._chk(self.lib.lrn_schur_import_full(self.h, ptr(buf)), "lrn_schur_import_full")
+
     def schur_export_shard(self, buf):
         self._chk(self.lib.lrn_schur_export_shard(self.h, ptr(buf)), "lrn_schur_export_shard")
 

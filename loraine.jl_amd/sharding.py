@@ -78,6 +78,62 @@ def unpack_all(buf_all, nvar, world, bs=SHARD_BS):
     return H
 
 
+# ------------------------------------------------------------------ kit = 0, dense data: column split of the matrix variable
+def column_tiles(msz, nd, rank, world):
+    """Executable specification of `col_tile_runs` (csrc/schur.hip): the 128-column tiles of the matrix variable a
+    rank owns on the Cholesky path.  With W = L L', column c of At_k = L' A_k L needs only columns >= c of L and A_k
+    and <At_i, At_j> is a sum over columns, so a rank computes ITS columns of every At_k and its share of every inner
+    product; the ranks' partial Schur matrices are added by one all-reduce.  Every rank gets one contiguous range of
+    tiles, chosen to minimise the largest load (dynamic programme, ties keep the smallest cut)."""
+    nt = (msz + 127) // 128
+    if world <= 1:
+        return list(range(nt))
+    S = (msz + 15) // 16 * 16
+
+    def off_base(c):
+        q = c >> 4
+        return 16 * (q * S - 8 * q * (q + 1)) + (c - 16 * q) * (S - 16 * (q + 1))
+
+    cost = []
+    for t in range(nt):
+        k1 = (nt - t) * (msz - 128.0 * t)
+        k2 = sum(msz - 128.0 * i for i in range(t, nt))
+        c0, c1 = 128 * t, min(msz, 128 * t + 128)
+        k3 = 16.0 * (c1 - c0) + (off_base(c1) - off_base(c0))
+        cost.append((k1 + k2) * 32768.0 + 0.5 * nd * k3 * 2.0)
+    P = min(world, nt)
+    pre = [0.0]
+    for t in range(nt):
+        pre.append(pre[-1] + cost[t])
+    INF = 1e300
+    dp = [[INF] * (nt + 1) for _ in range(P + 1)]
+    cut = [[0] * (nt + 1) for _ in range(P + 1)]
+    dp[0][0] = 0.0
+    for p in range(1, P + 1):
+        for j in range(p, nt + 1):
+            for i in range(p - 1, j):
+                seg = pre[j] - pre[i]
+                v = dp[p - 1][i] if dp[p - 1][i] > seg else seg
+                if v < dp[p][j]:
+                    dp[p][j], cut[p][j] = v, i
+    lo, hi, j = [0] * P, [0] * P, nt
+    for p in range(P, 0, -1):
+        lo[p - 1], hi[p - 1] = cut[p][j], j
+        j = cut[p][j]
+    return list(range(lo[rank], hi[rank])) if rank < P else []
+
+
+def partial_schur_dense(Amats, W, rank, world):
+    """NumPy restatement of one rank's partial sum on the Cholesky path (tests): H_g[i,j] = sum over the rank's
+    columns c of <At_i[:,c], At_j[:,c]>, At_k = L' A_k L."""
+    L = np.linalg.cholesky(W)
+    msz = W.shape[0]
+    cols = np.concatenate([np.arange(128 * t, min(msz, 128 * t + 128)) for t in column_tiles(msz, len(Amats), rank, world)]
+                          or [np.zeros(0, dtype=int)]).astype(int)
+    At = np.stack([(L.T @ a @ L)[:, cols] for a in Amats]).reshape(len(Amats), -1)
+    return At @ At.T
+
+
 class SchurExchange:
     """The collective step of the sharded direct solve (product path, GPU tensors)."""
 
@@ -89,10 +145,31 @@ class SchurExchange:
         self.shard = torch.zeros(n, dtype=torch.float64, device="cuda")
         self.gathered = torch.zeros(n * world, dtype=torch.float64, device="cuda")
 
+    def allreduce_full(self):
+        """Dense data through the Cholesky factor of W: every rank holds a partial sum of the whole matrix
+        (the ranks split the columns of the matrix variable) -- one all-reduce of nvar^2 doubles."""
+        import torch
+        import torch.distributed as dist
+        n = self.dev.nvar
+        if getattr(self, "full", None) is None or self.full.numel() != n * n:
+            self.full = torch.zeros(n * n, dtype=torch.float64, device="cuda")
+        self.dev.schur_export_full(self.full)
+        if dist.get_backend(self.group) == "gloo":        # rehearsal on a one-GPU box: stage through the host
+            h_ = self.full.cpu()
+            dist.all_reduce(h_, group=self.group)
+            self.full.copy_(h_)
+            torch.cuda.synchronize()
+        else:
+            dist.all_reduce(self.full, group=self.group)   # RCCL over xGMI
+            torch.cuda.current_stream().synchronize()
+        self.dev.schur_import_full(self.full)
+
     def allgather(self):
         import torch
         import torch.distributed as dist
         self.dev.set_shard(self.rank, self.world)
+        if self.dev.schur_is_partial_sum():
+            return self.allreduce_full()
         self.dev.schur_export_shard(self.shard)
         if dist.get_backend(self.group) == "gloo":        # rehearsal on a one-GPU box: stage through the host
             g_host = torch.empty(self.gathered.shape, dtype=torch.float64)

@@ -375,35 +375,47 @@ def test_chol_path_two_blocks_and_switching(dev):
         dev.set_option("schur_chol", -1)
 
 
-def test_chol_path_sharded_two_ranks(dev):
-    """world = 2 takes the Cholesky path too (replicated L' A_k L, owned column blocks of the rank-k
-    update): the shards glued by the exchange layout equal the one-rank matrix."""
+@pytest.mark.parametrize("msz,nvar,world", [(260, 300, 2), (260, 300, 3), (260, 300, 5), (1000, 160, 3), (1000, 160, 8)])
+def test_chol_path_column_split_partial_sums(dev, msz, nvar, world):
+    """world > 1 on the Cholesky path: the ranks split the 128-column tiles of the matrix variable (all three GEMMs
+    shard) and hold partial sums of the whole Schur matrix; their sum (the all-reduce) is the one-rank matrix.  Also
+    more ranks than tiles (idle ranks contribute zero), and the tile dealing equals its Python specification."""
     import torch
-    msz, nvar = 260, 300
+    from loraine_jl_amd import sharding
     dev.synthetic_dense_model(msz, nvar, 11)
-    W, G = _spd(msz, 12)
+    W, G = _spd(msz, 12, cond=1e4)
     dev.set_scaling(0, W, G)
     Hfull = dev.schur_assemble(0, want_H=True)
-    parts = []
+    assert not dev.schur_is_partial_sum()
+    total = torch.zeros(nvar * nvar, dtype=torch.float64, device="cuda")
+    buf = torch.zeros(nvar * nvar, dtype=torch.float64, device="cuda")
+    shares = 0.0
     try:
-        for r in range(2):
-            dev.set_shard(r, 2)
+        for r in range(world):
+            dev.set_shard(r, world)
             dev.reset_timing()
             dev.schur_assemble(0)
-            assert dev.count("schur_chol") == 1
-            buf = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
-            dev.schur_export_shard(buf)
-            parts.append(buf)
-        dev.schur_import_all(torch.cat(parts))
+            assert dev.count("schur_chol") == 1 and dev.schur_is_partial_sum()
+            tiles = sharding.column_tiles(msz, nvar, r, world)
+            assert (dev.timing("gemm3_share") > 0) == (len(tiles) > 0)
+            shares += dev.timing("gemm3_share")
+            dev.schur_export_full(buf)
+            torch.cuda.synchronize()
+            total += buf
+        torch.cuda.synchronize()
+        dev.schur_import_full(total)
+        assert not dev.schur_is_partial_sum()
         H2 = dev.schur_get()
     finally:
         dev.set_shard(0, 1)
-    assert relerr(H2, Hfull) < 1e-14
+    assert shares == pytest.approx(1.0, abs=1e-12)       # the ranks' K ranges tile the packed index exactly
+    assert relerr(H2, Hfull) < 1e-13
+    assert dev.schur_factor() == 0
 
 
 def test_via_l_path_sharded_three_ranks(dev):
-    """world = 3: the ranks run the W path with T_k = L (L' A_k L) L' for their own columns; the shards glued by
-    the exchange layout equal the one-rank matrix (which took the Cholesky path)."""
+    """world = 3 with the T_k form forced: the ranks run the W path with T_k = L (L' A_k L) L' for their own Schur
+    columns; the shards glued by the exchange layout equal the one-rank matrix (which took the Cholesky path)."""
     import torch
     msz, nvar = 300, 420
     dev.synthetic_dense_model(msz, nvar, 13)
@@ -413,12 +425,13 @@ def test_via_l_path_sharded_three_ranks(dev):
     Hfull = dev.schur_assemble(0, want_H=True)
     assert dev.count("schur_chol") == 1
     parts = []
+    dev.set_option("schur_chol", 2)              # (auto would take the column split of the Cholesky path)
     try:
         for r in range(3):
             dev.set_shard(r, 3)
             dev.reset_timing()
             dev.schur_assemble(0)
-            assert dev.count("schur_chol") == 0 and dev.count("schur_via_l") > 0
+            assert dev.count("schur_chol") == 0 and dev.count("schur_via_l") > 0 and not dev.schur_is_partial_sum()
             buf = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
             dev.schur_export_shard(buf)
             parts.append(buf)
@@ -426,6 +439,7 @@ def test_via_l_path_sharded_three_ranks(dev):
         H2 = dev.schur_get()
     finally:
         dev.set_shard(0, 1)
+        dev.set_option("schur_chol", -1)
     assert relerr(H2, Hfull) < 1e-13
     A = np.stack([dev.get_constraint(0, k) for k in range(0, nvar, 60)])
     assert relerr(H2[::60, ::60], _brute_H(A, W)) < 1e-13

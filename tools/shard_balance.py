@@ -22,7 +22,7 @@ for world in (1, 2, 4, 8):
         dev.schur_assemble(0)                      # warm-up (workspace sizes)
         dev.reset_timing(); dev.schur_assemble(0)
         ts.append(dev.timing("assemble"))
-        if world == 8:
+        if world in (4, 8):
             print(f"   rank {r}: gemm1 {dev.timing('gemm1'):.1f} gemm2 {dev.timing('gemm2'):.1f} gemm3 {dev.timing('gemm3'):.1f} launches {dev.count('gemm1')}/{dev.count('gemm2')}/{dev.count('gemm3')}", flush=True)
     print(f"world {world} (shard_bs {bs_now}): per-rank assembly ms min {min(ts):.1f} max {max(ts):.1f}  ideal {ts and (sum(ts)/world):.1f}  "
           f"(1-GPU time / world = {base/world:.1f})" if world > 1 else f"world 1: {ts[0]:.1f} ms", flush=True)
