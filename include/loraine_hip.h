@@ -68,7 +68,7 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * constraint is sparse), "svd_sdc" (0/1,
  * experimental divide-and-conquer start of the SVD for msz >= "sdc_min"; "sdc_leaf", "sdc_l0"),
  * "schur_chol" (dense Schur assembly through the Cholesky factor of W: -1 auto -- H_ij = <L'A_iL, L'A_jL> when
- * every constraint of the block is dense and world <= 2, T_k = L (L'A_kL) L' otherwise, both for msz >= 256 --,
+ * every constraint of the block is dense, T_k = L (L'A_kL) L' otherwise, both for msz >= 256 --,
  * 0 never (T_k = W A_k W), 1 as auto without the size threshold, 2 the T_k form only),
  * "gemm3_ksplit" (split-K factor of the inner-product GEMM, 0 = auto), "gemm3_stagger" (experiment: K-walk stagger of
  * the workgroups of GEMM3' in chunks of 16, 0 = off),

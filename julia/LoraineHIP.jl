@@ -234,6 +234,13 @@ export_shard!(ctx::Ctx, buf::Ptr{Float64}) =
     check(ctx, ccall((:lrn_schur_export_shard, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, buf), "lrn_schur_export_shard")
 import_all!(ctx::Ctx, buf_all::Ptr{Float64}) =
     check(ctx, ccall((:lrn_schur_import_all, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, buf_all), "lrn_schur_import_all")
+# dense data on several GPUs: every rank holds a partial SUM of the Schur matrix (the ranks split the columns of the
+# matrix variable); exchange = export_full! -> all-reduce(sum) of nvar^2 doubles -> import_full!
+is_partial_sum(ctx::Ctx) = ccall((:lrn_schur_is_partial_sum, LIB), Cint, (Ptr{Cvoid},), ctx.h) != 0
+export_full!(ctx::Ctx, buf::Ptr{Float64}) =
+    check(ctx, ccall((:lrn_schur_export_full, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, buf), "lrn_schur_export_full")
+import_full!(ctx::Ctx, buf::Ptr{Float64}) =
+    check(ctx, ccall((:lrn_schur_import_full, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, buf), "lrn_schur_import_full")
 function matvec_partial!(ctx::Ctx, Ax::Vector{Float64}, x::Vector{Float64})   # caller all-reduces Ax
     check(ctx, ccall((:lrn_matvec_partial, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, x, Ax), "lrn_matvec_partial")
 end
