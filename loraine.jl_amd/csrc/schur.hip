@@ -357,6 +357,8 @@ static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
   if (b.npos_nz != b.nd || b.nd < 2 || b.msz < 2) return false;   // sparse partners gather from T_k = W A_k W itself
   if (opt_schur_chol < 0 && b.msz < 256) return false;
   if (c->world > 1 && !c->pos_space) return false;
+  // the column split deals 128-column tiles: with fewer tiles than ranks the Schur column blocks (all ranks busy) win
+  if (c->world > 1 && opt_schur_chol < 0 && (b.msz + 127) / 128 < c->world) return false;
   const long mm = (long)b.msz * b.msz;
   long pcap = opt_p_batch > 0 ? opt_p_batch : tri_p_batch(b.msz);
   if (pcap > b.nd) pcap = b.nd;

@@ -390,6 +390,7 @@ def test_chol_path_column_split_partial_sums(dev, msz, nvar, world):
     total = torch.zeros(nvar * nvar, dtype=torch.float64, device="cuda")
     buf = torch.zeros(nvar * nvar, dtype=torch.float64, device="cuda")
     shares = 0.0
+    dev.set_option("schur_chol", 1)             # (auto keeps the Schur column blocks when ranks outnumber the tiles)
     try:
         for r in range(world):
             dev.set_shard(r, world)
@@ -408,6 +409,7 @@ def test_chol_path_column_split_partial_sums(dev, msz, nvar, world):
         H2 = dev.schur_get()
     finally:
         dev.set_shard(0, 1)
+        dev.set_option("schur_chol", -1)
     assert shares == pytest.approx(1.0, abs=1e-12)       # the ranks' K ranges tile the packed index exactly
     assert relerr(H2, Hfull) < 1e-13
     assert dev.schur_factor() == 0
@@ -466,3 +468,22 @@ def test_chol_path_split_and_stagger_knobs(dev, ksplit, stagger):
     assert relerr(H1, H0) < 1e-14
     A = np.stack([dev.get_constraint(0, k) for k in range(0, nvar, 30)])
     assert relerr(H1[::30, ::30], _brute_H(A, W)) < 1e-13
+
+
+def test_auto_mode_keeps_column_blocks_when_ranks_outnumber_tiles(dev):
+    """msz 260 = 3 column tiles: with 5 ranks the automatic choice is the Schur column-block sharding (T_k through
+    the factor), with 2 ranks the column split of the matrix variable."""
+    dev.synthetic_dense_model(260, 40, 3)
+    W, G = _spd(260, 4)
+    dev.set_scaling(0, W, G)
+    try:
+        dev.set_shard(0, 5)                      # (rank 0 owns the only 128-wide Schur column block of nvar = 40)
+        dev.reset_timing()
+        dev.schur_assemble(0)
+        assert not dev.schur_is_partial_sum() and dev.count("schur_via_l") > 0
+        dev.set_shard(1, 2)
+        dev.reset_timing()
+        dev.schur_assemble(0)
+        assert dev.schur_is_partial_sum() and dev.count("schur_chol") == 1
+    finally:
+        dev.set_shard(0, 1)
