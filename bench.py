@@ -247,7 +247,7 @@ def main():
         own = owned_columns(nvar, rank, world, bs=dev.shard_bs())
         nown = len(own)
         chol_path = dev.count("schur_chol") > 0
-        via_l = dev.count("schur_via_l") > 0                        # W path with T_k = L (L'A_kL) L'  (>= 3 ranks)
+        via_l = dev.count("schur_via_l") > 0                        # W path with T_k = L (L'A_kL) L'  (mixed data / forced)
         per_step = {k: dev.timing(k) / args.steps for k in ("gemm1", "gemm2", "gemm3")}
         dom = max(per_step, key=per_step.get)                       # dominant kernel of this run
         nl = max(1, dev.count(dom))

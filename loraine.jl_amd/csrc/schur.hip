@@ -578,8 +578,8 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   const int m = b.msz, nd = b.nd, n = c->nvar;
   const long mm = (long)m * m;
   // Both fast paths need W = L L'.  via_l: the W path below forms T_k = L (L' A_k L) L' on triangular K ranges
-  // (4 products, 2 msz^3 flop) instead of W (A_k W) (2 products, 3 msz^3); this is what ranks of a >= 3-GPU job and
-  // blocks with sparse constraints run.  option schur_chol: -1 auto, 0 never factor W, 1 as auto without the size
+  // (4 products, 2 msz^3 flop) instead of W (A_k W) (2 products, 3 msz^3); this is what blocks that also hold sparse
+  // constraints run (on any number of ranks, Schur column blocks).  option schur_chol: -1 auto, 0 never factor W, 1 as auto without the size
   // thresholds, 2 T-via-L only.
   bool via_l = false;
   {
