@@ -7,11 +7,15 @@ One "step" = one pass of the hot path over one iterate: assemble H (GEMM1/2/3 on
 MFMA; on one or two ranks through the Cholesky factor of W), factor it
 (blocked Cholesky) and run the predictor and corrector solves.  Inputs
 (constraint data, NT scaling W, right-hand sides) are resident in HBM when the timed region
-starts.  N > 1: one process per GPU (torchrun); the ranks split the columns of the matrix variable
+starts.  N > 1: one process per GPU; the ranks split the columns of the matrix variable
 (every GEMM of the assembly shards) and one RCCL all-reduce adds their partial Schur matrices before
 the replicated factorisation; total work is fixed (`"scaling": "strong"`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--msz 2000] [--nvar 4000]
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N`) BEFORE anything touches a GPU and forwards their
+output and exit code; launched under torchrun it is one rank.  WORLD_SIZE != --gpus is an error.
 """
 import argparse
 import json
@@ -127,18 +131,41 @@ def cpu_baseline(msz, nvar, seed):
     }
 
 
+def self_launch(args):
+    """--gpus N > 1 without a torchrun environment: this process becomes the launcher.  It starts the N ranks as
+    children, never imports torch or touches a GPU itself, forwards the ranks' output (rank 0 prints the JSON line)
+    and exits with their exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
 def main():
     args = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     # rehearsal knobs (1-GPU box): LRN_BENCH_BACKEND=gloo LRN_BENCH_ONE_GPU=1 run all ranks on
     # device 0 and stage the exchange through host memory; the driver's runs use RCCL.
     backend = os.environ.get("LRN_BENCH_BACKEND", "nccl")
@@ -169,17 +196,25 @@ def main():
     h_pred = torch.from_numpy(rng.standard_normal(nvar)).cuda()
     h_corr = torch.from_numpy(rng.standard_normal(nvar)).cuda()
     dely = torch.zeros(nvar, dtype=torch.float64, device="cuda")
+    from loraine_jl_amd import sharding
     if sharded:
         dev.set_shard(rank, world)
+        # every rank must enter the same collective: agree on the exchange before the first assembly (free device
+        # memory, which the choice depends on, differs between ranks) and check the outcome of every assembly
+        plan = sharding.agree_on_plan(dev)
         shard = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
         gathered = torch.zeros(dev.shard_doubles() * world, dtype=torch.float64, device="cuda")
         hfull = torch.zeros(nvar * nvar, dtype=torch.float64, device="cuda")
     from loraine_jl_amd._capi import ptr
     lib = dev.lib
 
+    t_exchange = [0.0]
+
     def step():
         dev.schur_assemble(0)                                   # makeBBBBs on the owned columns
-        if sharded and dev.schur_is_partial_sum():
+        te = time.perf_counter()
+        partial = sharding.check_same_exchange(dev) if sharded else False
+        if sharded and partial:
             # Cholesky path: the ranks split the columns of the matrix variable, each holds a partial sum of H
             dev.schur_export_full(hfull)
             if backend == "nccl":
@@ -202,6 +237,7 @@ def main():
                 gathered.copy_(g_host)
                 torch.cuda.synchronize()
             dev.schur_import_all(gathered)
+        t_exchange[0] += time.perf_counter() - te               # (includes waiting for the slowest rank's assembly)
         info = dev.schur_factor()                               # cholesky(BBBB)
         assert info == 0, f"Schur matrix not PD (info={info})"
         dev._chk(lib.lrn_schur_solve(dev.h, ptr(h_pred), ptr(dely)), "solve")   # predictor
@@ -223,6 +259,7 @@ def main():
         step()
     dev.set_option("profile", 1)          # per-kernel HIP-event timing on the library's stream
     dev.reset_timing()
+    t_exchange[0] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -242,14 +279,14 @@ def main():
         chks = [None] * world
         dist.all_gather_object(chks, chk)
         assert all(c_ == chks[0] for c_ in chks), f"ranks disagree on dely: {chks}"
-    if rank == 0:
-        from loraine_jl_amd.sharding import owned_columns
-        own = owned_columns(nvar, rank, world, bs=dev.shard_bs())
+    # ---- every rank prices ITS dominant kernel; the line reports the slowest rank (the one the step waits for)
+    def rank_report():
+        own = sharding.owned_columns(nvar, rank, world, bs=dev.shard_bs())
         nown = len(own)
         chol_path = dev.count("schur_chol") > 0
         via_l = dev.count("schur_via_l") > 0                        # W path with T_k = L (L'A_kL) L'  (mixed data / forced)
         per_step = {k: dev.timing(k) / args.steps for k in ("gemm1", "gemm2", "gemm3")}
-        dom = max(per_step, key=per_step.get)                       # dominant kernel of this run
+        dom = max(per_step, key=per_step.get)                       # dominant kernel of this rank
         nl = max(1, dev.count(dom))
         t1 = dev.timing(dom) / nl                                   # ms per launch (HIP events on the library's stream)
         launches_per_step = nl / args.steps
@@ -285,12 +322,34 @@ def main():
                      else "gemm_f64_lds_kernel<true> GEMM2 (lower tiles)")
             kpat = "gemm_f64_lds_kernel<true>"
         achieved = alg_flops_launch / (t1 * 1e-3) / 1e12
-        probe = dev.mfma_f64_peak()
         phases = {k: dev.timing(k) / args.steps
                   for k in ("wchol", "gemm1", "gemm2", "gemm3", "reduce3", "assemble", "factor", "solve")}
+        cols = sharding.column_range(msz, nvar, rank, world) if chol_path else None
+        return {"rank": rank, "chol_path": chol_path, "via_l": via_l, "kpat": kpat, "phases": phases,
+                "columns": list(cols) if cols else None,
+                "shares": {k: dev.timing(k + "_share") for k in ("gemm1", "gemm2", "gemm3")} if chol_path else None,
+                "roofline": {"bound": "mfma", "kernel": kname, "rank": rank,
+                             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                             "avg_launch_ms": t1, "launches_per_step": launches_per_step,
+                             "alg_flops_per_launch": alg_flops_launch}}
+
+    mine = rank_report()
+    reports = [mine]
+    if sharded:
+        reports = [None] * world
+        dist.all_gather_object(reports, mine)
+    if rank == 0:
+        slow = max(reports, key=lambda r_: r_["phases"]["assemble"])          # the rank the step waits for
+        chol_path, via_l = slow["chol_path"], slow["via_l"]
+        roof = slow["roofline"]
+        if (msz, nvar, world) == (2000, 4000, 1):
+            roof["traffic"] = pmc_traffic_bytes(slow["kpat"])
+        roof["peak_probe"] = dev.mfma_f64_peak()
         out = {
             "metric": "ms/IP-iteration (Schur assembly + solve), dense SDP n=2000 m=4000",
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ranks_seen": dist.get_world_size() if sharded else 1,
             "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C4 synthetic dense SDP, matrix side {msz}, {nvar} constraints, kit=0 "
@@ -302,16 +361,17 @@ def main():
             "algorithmic_tflops": flops_model(msz, nvar) / (ms_per_step * 1e-3) / 1e12,
             "assembly_path": ("cholesky (H_ij = <L'A_iL, L'A_jL>, W = LL')" if chol_path
                               else ("T_k = L (L'A_kL) L', W = LL'" if via_l else "T_k = W A_k W")),
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic_bytes(kpat) if (msz, nvar, world) == (2000, 4000, 1) else None,
-                         "peak_probe": probe, "avg_launch_ms": t1, "launches_per_step": launches_per_step,
-                         "alg_flops_per_launch": alg_flops_launch},
-            "phase_ms_per_step": phases,
+            "roofline": roof,
+            "phase_ms_per_step": slow["phases"],
             "dely_checksum": chk,
             "data_gen_s": t_gen,
         }
+        if world > 1:
+            out["per_rank"] = [{"rank": r_["rank"], "columns": r_["columns"], "assemble_ms": r_["phases"]["assemble"],
+                                "gemm1_ms": r_["phases"]["gemm1"], "gemm2_ms": r_["phases"]["gemm2"],
+                                "gemm3_ms": r_["phases"]["gemm3"], "roofline_frac": r_["roofline"]["frac"]}
+                               for r_ in reports]
+            out["exchange_ms_per_step"] = t_exchange[0] / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             dev.close()
             out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7)

@@ -109,6 +109,14 @@ int lrn_schur_import_all(lrn_ctx* ctx, const double* buf_all);
  * (buffers host or device, position space, lower triangle authoritative).  When it returns 0 the owned column
  * blocks are exchanged with export_shard / all-gather / import_all as above. */
 int lrn_schur_is_partial_sum(lrn_ctx* ctx);
+/* multi-GPU: which of the two exchanges the next lrn_schur_assemble(mode) of THIS rank would need, from its own view
+ * (options, data layout, world size, free device memory): *plan = 1 partial sums + all-reduce, 0 column blocks +
+ * all-gather.  Free memory can differ between ranks, so the host all-reduces (MIN) the answers once after
+ * lrn_set_shard and pins the result on every rank with lrn_set_option("schur_plan", 0 or 1); a pinned plan is not
+ * re-decided by the assembly (a rank that then cannot allocate fails loudly instead of entering another
+ * collective).  The reference has no counterpart (single process); this belongs to the sharded loop of
+ * src/makeBBBB.jl:77-101. */
+int lrn_schur_plan(lrn_ctx* ctx, int mode, int* plan);
 int lrn_schur_export_full(lrn_ctx* ctx, double* buf);
 int lrn_schur_import_full(lrn_ctx* ctx, const double* buf);
 

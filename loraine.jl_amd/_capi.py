@@ -45,6 +45,7 @@ SIGNATURES = {
     "lrn_schur_export_shard": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_schur_import_all": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_schur_is_partial_sum": (C.c_int, [c_ctx]),
+    "lrn_schur_plan": (C.c_int, [c_ctx, C.c_int, PI]),
     "lrn_schur_export_full": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_schur_import_full": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_make_rhs": (C.c_int, [c_ctx, C.c_void_p, PPD, C.c_void_p]),
@@ -100,9 +101,14 @@ def load_library():
         # a fresh checkout on a box with the ROCm toolchain: compile the HIP sources once (this is the
         # product library itself, not a fallback)
         csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-        print(f"[loraine.jl_amd] {LIB_PATH} missing: running `make -C {csrc}` (hipcc --offload-arch=gfx950)",
-              file=sys.stderr, flush=True)
-        subprocess.run(["make", "-C", csrc, "-j8"], check=False, stdout=subprocess.DEVNULL)
+        # one builder at a time: every rank of a torchrun job lands here together
+        import fcntl
+        with open(os.path.join(csrc, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if not os.path.exists(LIB_PATH):
+                print(f"[loraine.jl_amd] {LIB_PATH} missing: running `make -C {csrc}` (hipcc --offload-arch=gfx950)",
+                      file=sys.stderr, flush=True)
+                subprocess.run(["make", "-C", csrc, "-j8"], check=False, stdout=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise LoraineHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -7,20 +7,8 @@
 using namespace lrn;
 
 void lrn_free_model(lrn_ctx* c);
-extern double lrn_opt_dense_threshold;
 namespace lrn {
-void set_batch_opts(long t, long p);
 void prec_free(lrn_ctx* c);
-extern bool opt_jacobi_warm;
-extern int opt_prec_eig;
-extern int opt_matvec_sparse;
-extern int opt_jacobi_inner;
-extern int opt_jacobi_block;
-extern int opt_jacobi_wgs;
-extern int opt_svd_sdc, opt_sdc_min, opt_sdc_leaf;
-extern double opt_sdc_l0;
-extern double opt_pivot_boost;
-extern int opt_schur_chol, opt_gemm3_ksplit, opt_gemm3_stagger;
 }
 
 extern "C" {
@@ -76,28 +64,35 @@ int lrn_destroy(lrn_ctx* c) {
   return LRN_OK;
 }
 
-const char* lrn_last_error(lrn_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* lrn_last_error(lrn_ctx* c) {
+  if (!c) return "null context";
+  if (const char* g = lrn::gemm_last_error()) {        // gemm() cannot reach the context: append its reason once
+    if (c->err.find(g) == std::string::npos) c->err += std::string(c->err.empty() ? "" : " | ") + g;
+  }
+  return c->err.c_str();
+}
 
 int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   if (!c || !key) return LRN_ERR_ARG;
-  if (!strcmp(key, "dense_threshold")) lrn_opt_dense_threshold = value;
+  if (!strcmp(key, "dense_threshold")) c->opt.dense_threshold = value;
   else if (!strcmp(key, "profile")) c->profile = value != 0.0;
-  else if (!strcmp(key, "t_batch")) { set_batch_opts((long)value, -1); for (auto& b : c->lmi) b.t_cap = b.p_cap = 0; }
-  else if (!strcmp(key, "p_batch")) { set_batch_opts(-1, (long)value); for (auto& b : c->lmi) b.t_cap = b.p_cap = 0; }
-  else if (!strcmp(key, "prec_eig")) lrn::opt_prec_eig = (int)value;
-  else if (!strcmp(key, "pivot_boost")) lrn::opt_pivot_boost = value;
-  else if (!strcmp(key, "schur_chol")) lrn::opt_schur_chol = (int)value;
-  else if (!strcmp(key, "gemm3_ksplit")) lrn::opt_gemm3_ksplit = (int)value;
-  else if (!strcmp(key, "gemm3_stagger")) lrn::opt_gemm3_stagger = (int)value;
-  else if (!strcmp(key, "svd_sdc")) lrn::opt_svd_sdc = (int)value;
-  else if (!strcmp(key, "sdc_min")) lrn::opt_sdc_min = (int)value;
-  else if (!strcmp(key, "sdc_leaf")) lrn::opt_sdc_leaf = (int)value;
-  else if (!strcmp(key, "sdc_l0")) lrn::opt_sdc_l0 = value;
-  else if (!strcmp(key, "jacobi_wgs")) lrn::opt_jacobi_wgs = (int)value;
-  else if (!strcmp(key, "jacobi_block")) lrn::opt_jacobi_block = (int)value;
-  else if (!strcmp(key, "jacobi_inner")) lrn::opt_jacobi_inner = (int)value;
-  else if (!strcmp(key, "matvec_sparse")) lrn::opt_matvec_sparse = (int)value;
-  else if (!strcmp(key, "jacobi_warm")) lrn::opt_jacobi_warm = value != 0.0;
+  else if (!strcmp(key, "t_batch")) { c->opt.t_batch = (long)value; for (auto& b : c->lmi) b.t_cap = b.p_cap = 0; }
+  else if (!strcmp(key, "p_batch")) { c->opt.p_batch = (long)value; for (auto& b : c->lmi) b.t_cap = b.p_cap = 0; }
+  else if (!strcmp(key, "prec_eig")) c->opt.prec_eig = (int)value;
+  else if (!strcmp(key, "pivot_boost")) c->opt.pivot_boost = value;
+  else if (!strcmp(key, "schur_chol")) c->opt.schur_chol = (int)value;
+  else if (!strcmp(key, "schur_plan")) c->opt.schur_plan = (int)value;
+  else if (!strcmp(key, "gemm3_ksplit")) c->opt.gemm3_ksplit = (int)value;
+  else if (!strcmp(key, "gemm3_stagger")) c->opt.gemm3_stagger = (int)value;
+  else if (!strcmp(key, "svd_sdc")) c->opt.svd_sdc = (int)value;
+  else if (!strcmp(key, "sdc_min")) c->opt.sdc_min = (int)value;
+  else if (!strcmp(key, "sdc_leaf")) c->opt.sdc_leaf = (int)value;
+  else if (!strcmp(key, "sdc_l0")) c->opt.sdc_l0 = value;
+  else if (!strcmp(key, "jacobi_wgs")) c->opt.jacobi_wgs = (int)value;
+  else if (!strcmp(key, "jacobi_block")) c->opt.jacobi_block = (int)value;
+  else if (!strcmp(key, "jacobi_inner")) c->opt.jacobi_inner = (int)value;
+  else if (!strcmp(key, "matvec_sparse")) c->opt.matvec_sparse = (int)value;
+  else if (!strcmp(key, "jacobi_warm")) c->opt.jacobi_warm = value != 0.0;
   else if (!strcmp(key, "shard_bs")) { if (value < 0) return LRN_ERR_ARG; c->shard_bs_opt = (int)value; lrn::update_shard_bs(c); }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }
   else return set_error(c, LRN_ERR_ARG, "unknown option %s", key);
@@ -116,6 +111,7 @@ int lrn_set_shard(lrn_ctx* c, int rank, int world) {
 
 int lrn_set_scaling(lrn_ctx* c, int il, const double* W, const double* G) {
   if (!c || il < 0 || il >= c->nlmi || !W) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
   LmiBlock& b = c->lmi[il];
   size_t mm = (size_t)b.msz * b.msz * 8;
   LRN_TRY(copy_in(c, b.W.p, W, mm));
@@ -131,6 +127,7 @@ int lrn_set_lin(lrn_ctx* c, const double* X_lin, const double* S_lin_inv) {
   if (!c) return LRN_ERR_ARG;
   if (c->nlin == 0) return LRN_OK;
   if (!X_lin || !S_lin_inv) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
   // tiny vector: form the product on the host side of the boundary
   std::vector<double> x(c->nlin), s(c->nlin);
   if (is_device_ptr(X_lin)) {
@@ -154,10 +151,15 @@ int lrn_schur_assemble(lrn_ctx* c, int mode, double* H_out) {
 
 int lrn_schur_get(lrn_ctx* c, double* H_out) {
   if (!c || !H_out) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
   return schur_get(c, H_out);
 }
 
-int lrn_schur_add_diag(lrn_ctx* c, double eps) { return c ? schur_add_diag(c, eps) : LRN_ERR_ARG; }
+int lrn_schur_add_diag(lrn_ctx* c, double eps) {
+  if (!c) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  return schur_add_diag(c, eps);
+}
 
 int lrn_schur_factor(lrn_ctx* c, int* info) {
   if (!c) return LRN_ERR_ARG;
@@ -183,6 +185,14 @@ int64_t lrn_schur_shard_doubles(lrn_ctx* c) {
   int nblk, bpr;
   shard_geom(c, &nblk, &bpr);
   return (int64_t)bpr * c->shard_bs * c->nvar;
+}
+
+int lrn_schur_plan(lrn_ctx* c, int mode, int* plan) {
+  if (!c || !plan) return LRN_ERR_ARG;
+  if (c->nvar <= 0) return set_error(c, LRN_ERR_STATE, "no model uploaded");
+  LRN_HIP(c, hipSetDevice(c->device));
+  *plan = schur_plan(c, mode);
+  return LRN_OK;
 }
 
 int lrn_schur_is_partial_sum(lrn_ctx* c) { return c && c->have_H && c->H_partial ? 1 : 0; }
@@ -212,6 +222,7 @@ int lrn_schur_export_shard(lrn_ctx* c, double* buf) {
   if (c->H_partial)
     return set_error(c, LRN_ERR_STATE, "H holds a partial sum: exchange it with lrn_schur_export_full + all-reduce");
   if (!is_device_ptr(buf)) return set_error(c, LRN_ERR_ARG, "shard buffer must be device memory");
+  LRN_HIP(c, hipSetDevice(c->device));
   int nblk, bpr;
   shard_geom(c, &nblk, &bpr);
   const long n = c->nvar, bs = c->shard_bs;
@@ -233,6 +244,7 @@ int lrn_schur_export_shard(lrn_ctx* c, double* buf) {
 int lrn_schur_import_all(lrn_ctx* c, const double* buf_all) {
   if (!c || !buf_all) return LRN_ERR_ARG;
   if (!is_device_ptr(buf_all)) return set_error(c, LRN_ERR_ARG, "gathered buffer must be device memory");
+  LRN_HIP(c, hipSetDevice(c->device));
   int nblk, bpr;
   shard_geom(c, &nblk, &bpr);
   const long n = c->nvar, bs = c->shard_bs;

@@ -211,7 +211,6 @@ static int lin_matvec(lrn_ctx* c, const double* x, double* y) {
 //   Z[p,q] = W(:,p) . N(:,q)        -- two contiguous columns
 // and N' = W M is a sparse combination of columns of W:  N'(:,r) = sum_s M[s,r] W(:,s).
 // 2 nnz(M) msz + nnz(M) msz flop instead of 4 msz^3; the kernels are bandwidth-bound (L2 / MALL).
-int opt_matvec_sparse = 0;      // 0 auto, 1 dense GEMM path, 2 sparse path whenever the pattern allows
 
 __global__ __launch_bounds__(256) void sp_gather_kernel(const long* __restrict__ cq_ptr, const int* __restrict__ cq_j,
                                                         const double* __restrict__ cq_v, long ncq,
@@ -309,9 +308,9 @@ __global__ __launch_bounds__(256) void sp_aa_times_kernel(const long* __restrict
   if (lane == 0) out[sigma[p]] -= s;
 }
 
-static bool use_sparse_matvec(const LmiBlock& b) {
-  if (!b.sp_ok || opt_matvec_sparse == 1) return false;
-  if (opt_matvec_sparse == 2) return true;
+static bool use_sparse_matvec(const lrn_ctx* c, const LmiBlock& b) {
+  if (!b.sp_ok || c->opt.matvec_sparse == 1) return false;
+  if (c->opt.matvec_sparse == 2) return true;
   // ~4e-12 ncq msz s against 4 msz^3 / 6e13 s; below msz ~ 1500 both are launch-bound and the GEMM path
   // wins (thetaG11, msz = 801: 35 us per mat-vec)
   return b.msz >= 1500 && (double)b.ncq * 60.0 < (double)b.msz * (double)b.msz;
@@ -396,7 +395,7 @@ int matvec_dev(lrn_ctx* c, const double* x, double* y) {
   for (auto& b : c->lmi) {
     if (!b.have_W) return set_error(c, LRN_ERR_STATE, "W not set");
     const int m = b.msz;
-    if (use_sparse_matvec(b)) {
+    if (use_sparse_matvec(c, b)) {
       LRN_TRY(matvec_sparse_block(c, b, x, y, 0, m, true));
       continue;
     }
@@ -424,7 +423,7 @@ int matvec_partial_dev(lrn_ctx* c, const double* x, double* y, int rank, int wor
     const int r0 = std::min(m, rank * per), r1 = std::min(m, r0 + per);
     if (r1 <= r0) continue;
     const int nr = r1 - r0;
-    if (use_sparse_matvec(b)) {       // shard the pattern columns of Z instead of its rows
+    if (use_sparse_matvec(c, b)) {       // shard the pattern columns of Z instead of its rows
       LRN_TRY(matvec_sparse_block(c, b, x, y, r0, r1, false));
       continue;
     }
@@ -628,7 +627,6 @@ __global__ void add_eye_kernel(double* __restrict__ S, int n) {
   if (i < n) S[(long)i * n + i] += 1.0;
 }
 
-int opt_prec_eig = 0;     // 0 auto (Lanczos for msz >= 256), 1 Jacobi eigendecomposition, 2 Lanczos
 
 static double tau_of(const std::vector<double>& lam_s, int aamat) {
   // Solvers.jl:646-650 / :715-719
@@ -668,7 +666,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
     size_t mm = (size_t)m * m * 8;
     LRN_TRY(ensure(c, P->E, mm));
     LRN_TRY(ensure(c, P->sig, (size_t)m * 8));
-    const bool use_lz = opt_prec_eig == 2 || (opt_prec_eig == 0 && m >= 256);
+    const bool use_lz = c->opt.prec_eig == 2 || (c->opt.prec_eig == 0 && m >= 256);
     be[il].lanczos = use_lz;
     be[il].idx.resize(k);
     be[il].coef.resize(k);

@@ -55,8 +55,31 @@ struct LmiBlock {
 struct lrn_ctx;
 namespace lrn { void update_shard_bs(lrn_ctx* c); }
 
+// lrn_set_option knobs: per context (two contexts of one process -- Julia threads, tests -- do not see each
+// other's settings)
+struct LrnOptions {
+  double dense_threshold = -1.0;  // < 0: cost model decides which constraints are stored dense
+  long t_batch = 0, p_batch = 0;  // matrices per T workspace / per GEMM1-2 launch (0 = auto)
+  int prec_eig = 0;               // 0 auto (Lanczos for msz >= 256), 1 Jacobi eigendecomposition, 2 Lanczos
+  double pivot_boost = 0.0;       // lrn_schur_factor: 0 = strict LAPACK behaviour (the reference's), > 0 boosts
+                                  // pivots <= pivot_boost * diag (opt-in)
+  int schur_chol = -1;            // -1 auto, 0 never, 1 whenever the data allows it, 2 T-via-L only
+  int schur_plan = -1;            // multi-GPU: the exchange all ranks agreed on (-1 undecided, 0 all-gather of
+                                  // Schur column blocks, 1 all-reduce of partial sums); see lrn_schur_plan
+  int gemm3_ksplit = 0;           // split-K factor of GEMM3 / GEMM3' (0 = auto)
+  int gemm3_stagger = 0;          // K-walk stagger of GEMM3' in chunks of 16 (GemmDesc::kstagger)
+  int svd_sdc = 0, sdc_min = 4000, sdc_leaf = 768;
+  double sdc_l0 = 1e-6;
+  int jacobi_inner = 0;           // sweeps over the pair's Gram matrix per round (more did not cut the outer sweeps: 1)
+  int jacobi_wgs = 0;             // workgroups per Gram / apply launch the row chunking aims for: 0 auto
+  int jacobi_block = 0;           // column block width: 0 auto (32 for n >= 5000), 16, 32
+  bool jacobi_warm = true;
+  int matvec_sparse = 0;          // 0 auto, 1 dense GEMM path, 2 sparse path whenever the pattern allows
+};
+
 struct lrn_ctx {
   int device = 0;
+  LrnOptions opt;
   hipStream_t stream = nullptr;
   std::string err;
   int nlmi = 0, nvar = 0, nlin = 0;
@@ -115,6 +138,7 @@ void toc(lrn_ctx* c, const char* key);
 
 // schur.hip
 int schur_assemble(lrn_ctx* c, int mode);
+int schur_plan(lrn_ctx* c, int mode);
 int schur_factor(lrn_ctx* c, int* info);
 int schur_solve(lrn_ctx* c, const double* h, double* dely);
 int schur_add_diag(lrn_ctx* c, double eps);

@@ -20,6 +20,7 @@
 #include "lrn_common.h"
 
 #include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -544,6 +545,8 @@ static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count) {
   struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
   struct Val { int2* dev; int n; };
   static std::map<Key, Val> cache[16];
+  static std::mutex mu;                       // contexts on several host threads share the cache
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto& cm = cache[dev & 15];
@@ -568,13 +571,26 @@ static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count) {
   return val.dev;
 }
 
+// gemm() has no context to report into: the reason of its last failure on this thread, appended by
+// lrn_last_error (api.hip) so that a bare LRN_ERR_ARG from deep inside a driver is not a stale message
+static thread_local const char* tls_gemm_error = nullptr;
+const char* gemm_last_error() { return tls_gemm_error; }
+static int gemm_fail(int code, const char* why) { tls_gemm_error = why; return code; }
+
+static int gemm_impl(hipStream_t st, const GemmDesc& din);
 int gemm(hipStream_t st, const GemmDesc& din) {
+  const int rc = gemm_impl(st, din);
+  if (rc != LRN_OK && !tls_gemm_error) tls_gemm_error = "kernel launch failed";
+  return rc;
+}
+
+static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   GemmParams p;
   p.d = din;
   GemmDesc& d = p.d;
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return LRN_OK;
   if (d.ksplit < 1) d.ksplit = 1;
-  if (d.ksplit > MAX_KSPLIT) return LRN_ERR_ARG;
+  if (d.ksplit > MAX_KSPLIT) return gemm_fail(LRN_ERR_ARG, "gemm: d.ksplit > MAX_KSPLIT");
   // Orient so that the kernel's n (lane-contiguous in the MFMA result) is the contiguous
   // dimension of C: C^T = B^T A^T.
   long asCm = d.sCm < 0 ? -d.sCm : d.sCm, asCn = d.sCn < 0 ? -d.sCn : d.sCn;
@@ -598,14 +614,14 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   const bool kflat = d.flags & GEMM_KFLAT;
   const bool kseg = (d.flags & GEMM_KSEG_TRI) || kflat;
   const bool kfrom = d.flags & (GEMM_KFROM_N | GEMM_KFROM_M | GEMM_KTO_N | GEMM_KTO_M);   // triangular K ranges
-  if ((d.flags & GEMM_C_MIRROR) && (d.M != d.N || !tri || d.beta != 0.0)) return LRN_ERR_ARG;
+  if ((d.flags & GEMM_C_MIRROR) && (d.M != d.N || !tri || d.beta != 0.0)) return gemm_fail(LRN_ERR_ARG, "gemm: (d.flags & GEMM_C_MIRROR) && (d.M != d.N || !tri || d.beta != 0.0)");
   // triangular K ranges: the operand that is triangular spans K (a trailing sub-block may be narrower in the other
   // dimension: columns [c0, c1) of a product with the trailing block of the factor)
-  if (kfrom && (d.ksplit != 1 || kseg)) return LRN_ERR_ARG;
-  if ((d.flags & (GEMM_KFROM_N | GEMM_KTO_N)) && d.N > d.K) return LRN_ERR_ARG;
-  if ((d.flags & (GEMM_KFROM_M | GEMM_KTO_M)) && d.M > d.K) return LRN_ERR_ARG;
-  if ((d.flags & GEMM_C_PACKED) && (d.pk_off & 127)) return LRN_ERR_ARG;
-  if ((d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)) return LRN_ERR_ARG;
+  if (kfrom && (d.ksplit != 1 || kseg)) return gemm_fail(LRN_ERR_ARG, "gemm: kfrom && (d.ksplit != 1 || kseg)");
+  if ((d.flags & (GEMM_KFROM_N | GEMM_KTO_N)) && d.N > d.K) return gemm_fail(LRN_ERR_ARG, "gemm: (d.flags & (GEMM_KFROM_N | GEMM_KTO_N)) && d.N > d.K");
+  if ((d.flags & (GEMM_KFROM_M | GEMM_KTO_M)) && d.M > d.K) return gemm_fail(LRN_ERR_ARG, "gemm: (d.flags & (GEMM_KFROM_M | GEMM_KTO_M)) && d.M > d.K");
+  if ((d.flags & GEMM_C_PACKED) && (d.pk_off & 15)) return gemm_fail(LRN_ERR_ARG, "gemm: GEMM_C_PACKED needs pk_off % 16 == 0 (block width of the packed layout)");
+  if ((d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)) return gemm_fail(LRN_ERR_ARG, "gemm: (d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)");
   // tile choice: 128x128 unless the problem is too small to fill the chip with it
   long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit;
   bool small = (d.flags & GEMM_SMALL_TILE) ||
@@ -617,20 +633,19 @@ int gemm(hipStream_t st, const GemmDesc& din) {
     // chunk (16 doubles) boundaries per split: kflat_nsd splits over the diagonal region, the rest over
     // the strictly-lower region (the caller weights their slabs by 2)
     if (d.kflat_total <= 0 || d.kflat_diag <= 0 || d.kflat_diag > d.kflat_total || d.kflat_nsd < 1 ||
-        d.kflat_nsd > d.ksplit || d.kflat_cstride < 16 || (d.kflat_cstride & 1) || !kseg_lds_path_ok(d))
-      return LRN_ERR_ARG;
+        d.kflat_nsd > d.ksplit || d.kflat_cstride < 16 || (d.kflat_cstride & 1) || !kseg_lds_path_ok(d)) return gemm_fail(LRN_ERR_ARG, "gemm: d.kflat_total <= 0 || d.kflat_diag <= 0 || d.kflat_diag > d.kflat_total || d.kflat_nsd < 1 || d.kflat_nsd > d.ksplit || d.kflat_cstride < 16 || (d.kflat_cstride & 1) || !kseg_lds_path_ok(d)");
       d.K = (int)(d.kflat_total > 0x7fffffff ? 0x7fffffff : d.kflat_total);
     const long cd = d.kflat_diag / BK, ct = d.kflat_total / BK;
     // split s walks the chunks [kcols[s], kcols2[s])
     if (d.kflat_kb && d.kflat_ke) {
       for (int s = 0; s < d.ksplit; ++s) {
-        if (d.kflat_kb[s] < 0 || d.kflat_ke[s] < d.kflat_kb[s] || d.kflat_ke[s] > ct) return LRN_ERR_ARG;
+        if (d.kflat_kb[s] < 0 || d.kflat_ke[s] < d.kflat_kb[s] || d.kflat_ke[s] > ct) return gemm_fail(LRN_ERR_ARG, "gemm: d.kflat_kb[s] < 0 || d.kflat_ke[s] < d.kflat_kb[s] || d.kflat_ke[s] > ct");
         p.kcols[s] = d.kflat_kb[s];
         p.kcols2[s] = d.kflat_ke[s];
       }
     } else {
       const int nsd = d.kflat_nsd, nso = d.ksplit - nsd;
-      if ((nso == 0) != (ct == cd)) return LRN_ERR_ARG;
+      if ((nso == 0) != (ct == cd)) return gemm_fail(LRN_ERR_ARG, "gemm: (nso == 0) != (ct == cd)");
       for (int s = 0; s < nsd; ++s) { p.kcols[s] = (int)(cd * s / nsd); p.kcols2[s] = (int)(cd * (s + 1) / nsd); }
       for (int s = 0; s < nso; ++s) {
         p.kcols[nsd + s] = (int)(cd + (ct - cd) * s / nso);
@@ -639,7 +654,7 @@ int gemm(hipStream_t st, const GemmDesc& din) {
     }
     p.kchunk = 0;
   } else if (kseg) {
-    if (d.kseg_ld <= 0 || d.kseg_cols <= 0) return LRN_ERR_ARG;
+    if (d.kseg_ld <= 0 || d.kseg_cols <= 0) return gemm_fail(LRN_ERR_ARG, "gemm: d.kseg_ld <= 0 || d.kseg_cols <= 0");
     d.K = d.kseg_ld * d.kseg_cols;
     // balance splits by segment length sum
     double total = 0;
@@ -661,12 +676,12 @@ int gemm(hipStream_t st, const GemmDesc& din) {
   }
   int ntile = 0;
   p.tile_list = get_tile_list(p.tilesM, p.tilesN, d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER), &ntile);
-  if (!p.tile_list || ntile <= 0) return LRN_ERR_NOMEM;
+  if (!p.tile_list || ntile <= 0) return gemm_fail(LRN_ERR_NOMEM, "gemm: tile list allocation failed");
   (void)tri;
   const bool akc = (d.sAk == 1 && d.sAm != 1);
   const bool bkc = (d.sBk == 1 && d.sBn != 1);
   dim3 grid(ntile, 1, d.batch * d.ksplit);
-  if (grid.z > 65535) return LRN_ERR_ARG;
+  if (grid.z > 65535) return gemm_fail(LRN_ERR_ARG, "gemm: grid.z > 65535");
   const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE | GEMM_C_PACKED | GEMM_C_MIRROR);
   if (kflat) {
     hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true>), grid, dim3(256), 0, st, p);

@@ -154,9 +154,6 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(double* __restrict__ 
 //   jb_apply_kernel   P <- P R and V_panel <- V_panel R              (FP64 MFMA)
 // nbk-1 rounds make every pair of columns meet once per sweep.
 static constexpr int JB = 16;
-int opt_jacobi_inner = 0;     // sweeps over the pair's Gram matrix per round (more did not cut the outer sweeps: 1)
-int opt_jacobi_wgs = 0;       // workgroups per Gram / apply launch the row chunking aims for: 0 auto
-int opt_jacobi_block = 0;     // column block width: 0 auto (32 for n >= 5000; measured crossover between 4000 and 6000), 16, 32
 
 __global__ __launch_bounds__(256) void jb_gram_kernel(const double* __restrict__ A, int n, int nbk2, int round,
                                                       int RC, double* __restrict__ Gpart) {
@@ -596,13 +593,13 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
     LRN_HIP(c, hipStreamSynchronize(st));
   } else {
     if (V && !v_init) hipLaunchKernelGGL(set_identity_kernel, dim3(1024), dim3(256), 0, st, V, n);
-    const bool wide = opt_jacobi_block == 32 || (opt_jacobi_block == 0 && n >= 5000);
+    const bool wide = c->opt.jacobi_block == 32 || (c->opt.jacobi_block == 0 && n >= 5000);
     const int jb = wide ? JB2 : JB;
     const int gsz = wide ? 2560 : 768, rsz = wide ? 4096 : 1024;
     const int nbk = (n + jb - 1) / jb;
     const int nbk2 = (nbk + 1) & ~1;
     const int npair = nbk2 / 2;
-    const int wg_target = opt_jacobi_wgs > 0 ? opt_jacobi_wgs : (wide ? 1536 : (n < 1500 ? 256 : 512));
+    const int wg_target = c->opt.jacobi_wgs > 0 ? c->opt.jacobi_wgs : (wide ? 1536 : (n < 1500 ? 256 : 512));
     int nchunk = (wg_target + npair - 1) / npair;
     nchunk = std::max(1, std::min(nchunk, (n + 63) / 64));
     int RC = (n + nchunk - 1) / nchunk;
@@ -613,7 +610,7 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
     double* Rbuf = Gpart + (size_t)npair * nchunk * gsz;
     int* flags = reinterpret_cast<int*>(Rbuf + (size_t)npair * rsz);
     static const bool trace = getenv("LRN_JACOBI_TRACE") != nullptr;
-    const int inner = opt_jacobi_inner > 0 ? opt_jacobi_inner : 1;
+    const int inner = c->opt.jacobi_inner > 0 ? c->opt.jacobi_inner : 1;
     const size_t sh2 = (size_t)3 * 64 * 65 * 8 + 63 * 32 * 2;
     if (wide)
       LRN_HIP(c, hipFuncSetAttribute((const void*)jb2_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));

@@ -122,6 +122,7 @@ struct GemmDesc {
 };
 
 int gemm(hipStream_t st, const GemmDesc& d);
+const char* gemm_last_error();   // reason of this thread's last gemm() failure, or null
 // out[i] = beta*out[i] + sum_s slabs[s*stride + i]   (i < n), fixed summation order
 int reduce_slabs(hipStream_t st, const double* slabs, long stride, int nslab, double* out,
                  long n, double beta);

@@ -179,7 +179,6 @@ void lrn_free_model(lrn_ctx* c) {
   c->nlmi = c->nvar = c->nlin = 0;
 }
 
-double lrn_opt_dense_threshold = -1.0;   // < 0: cost model
 
 static int alloc_common(lrn_ctx* c) {
   size_t n = (size_t)c->nvar;
@@ -277,8 +276,8 @@ extern "C" int lrn_upload_model(lrn_ctx* c, int nlmi, int nvar, const int64_t* m
       int nd = 0;
       for (int p = 0; p < b.qA && p < b.npos_nz; ++p) {
         bool dense;
-        if (lrn_opt_dense_threshold >= 0) {
-          dense = (double)b.nnz[p] >= lrn_opt_dense_threshold;
+        if (c->opt.dense_threshold >= 0) {
+          dense = (double)b.nnz[p] >= c->opt.dense_threshold;
         } else {
           double pair_cost = (double)b.nnz[p] * suffix[p] / 1.0e11;
           double dense_cost = 3.0 * m * (double)m * m / 2.0e13 + (double)(nvar - p) * m * (double)m / 2.0e13 + 2e-5;

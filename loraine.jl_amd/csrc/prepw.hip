@@ -13,7 +13,6 @@
 #include "ops.h"
 
 namespace lrn {
-extern int opt_svd_sdc, opt_sdc_min;
 
 __global__ void tril_kernel(double* __restrict__ A, int n) {
   long total = (long)n * n;
@@ -93,7 +92,6 @@ static int gemm_nn(hipStream_t st, int n, const double* A, bool tA, const double
   return gemm(st, g);
 }
 
-bool opt_jacobi_warm = true;
 
 int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   const int n = b.msz;
@@ -132,7 +130,7 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   // SVD of CC = LS' LX = U D V' by one-sided Jacobi on CC' = LX' LS: its columns are rotated by
   // U and converge to V D, so V = (columns / D) needs no accumulation of rotations -- the rounds
   // are bandwidth-bound (every round streams the whole matrix), this removes the V half of it.
-  const bool use_sdc = opt_svd_sdc != 0 && n >= opt_sdc_min;
+  const bool use_sdc = c->opt.svd_sdc != 0 && n >= c->opt.sdc_min;
   int sweeps = 0;
   if (use_sdc) {
     // large msz: starting basis V0 from the spectral divide and conquer on K = CC' CC = L_X' S L_X
@@ -154,7 +152,7 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   LRN_TRY(gemm_nn(st, n, LX, true, LS, false, CC));
   // warm start: the left singular vectors of the previous IP iterate nearly orthogonalise the
   // columns of the new CC'
-  bool warm = b.have_Vprev && opt_jacobi_warm;
+  bool warm = b.have_Vprev && c->opt.jacobi_warm;
   if (warm) {
     LRN_TRY(gemm_nn(st, n, CC, false, b.Vprev.as<double>(), false, Y));
     LRN_HIP(c, hipMemcpyAsync(CC, Y, mm, hipMemcpyDeviceToDevice, st));
@@ -170,7 +168,7 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   // G = LX (V D^-1/2)
   hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 0, CC);
   LRN_TRY(gemm_nn(st, n, LX, false, CC, false, b.G.as<double>()));
-  if (opt_jacobi_warm && !use_sdc) {          // U = LS' G D^-1/2  (G = LS^-T U D^1/2) for the next warm start
+  if (c->opt.jacobi_warm && !use_sdc) {          // U = LS' G D^-1/2  (G = LS^-T U D^1/2) for the next warm start
     LRN_TRY(ensure(c, b.Vprev, mm));
     LRN_TRY(gemm_nn(st, n, LS, true, b.G.as<double>(), false, CC));
     hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, CC, b.D.as<double>(), n, 0,

@@ -191,7 +191,6 @@ __global__ void lin_schur_kernel(const int* __restrict__ pr, const int* __restri
   H[(long)ri + (long)rj * ldh] += s;
 }
 
-double opt_pivot_boost = 1e-12;     // 0 disables pivot boosting in lrn_schur_factor (strict LAPACK behaviour)
 
 __global__ void get_diag_kernel(const double* __restrict__ H, int n, double* __restrict__ d) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,13 +224,6 @@ __global__ void scatter_vec_kernel(const double* __restrict__ src, const int* __
 }
 
 // ------------------------------------------------------------------ host drivers
-static long opt_t_batch = 0, opt_p_batch = 0;
-int opt_gemm3_ksplit = 0;    // option "gemm3_ksplit": split-K factor of GEMM3 / GEMM3' (0 = auto)
-int opt_gemm3_stagger = 0;   // option "gemm3_stagger": K-walk stagger of GEMM3' in chunks of 16 (GemmDesc::kstagger)
-void set_batch_opts(long t, long p) {
-  if (t >= 0) opt_t_batch = t;
-  if (p >= 0) opt_p_batch = p;
-}
 
 static inline unsigned nblocks(long n, int per = 256, long cap = 4096) {
   long b = (n + per - 1) / per;
@@ -282,8 +274,7 @@ static long pick_p_batch(int m, long limit) {
 // The perturbation is that of a backward-stable Cholesky of W (||L L' - W|| <= c msz eps ||W||), the level W
 // itself is known to; when the factorisation of W breaks down (W numerically singular late in a solve) the
 // T_k = W A_k W path below takes over.  Multi-GPU: the columns of the matrix variable are dealt to the ranks
-// (col_tile_runs) -- all three GEMMs shard and the ranks' partial Schur matrices are summed by one all-reduce.
-int opt_schur_chol = -1;     // option "schur_chol": -1 auto, 0 never, 1 whenever the data allows it
+// (col_runs) -- all three GEMMs shard and the ranks' partial Schur matrices are summed by one all-reduce.
 
 // out[(i) + (j)*ldo] += sum_s w[s] * slab_s[i + j*M]  (lower 128-tiles; fixed order; weights 1 / 2 are exact)
 struct SlabWeights {
@@ -306,41 +297,52 @@ __global__ void reduce_slabs_w_kernel(const double* __restrict__ slabs, long str
 }
 
 // Multi-GPU split of the Cholesky path: the COLUMNS of the matrix variable.  Column c of every At_k = L' A_k L needs
-// only columns >= c of L and A_k, and <At_i, At_j> is a sum over columns -- so a rank that owns a set of 128-column
-// tiles computes those columns of every P_k and At_k and its share of every inner product: all three GEMMs shard, no
+// only columns >= c of L and A_k, and <At_i, At_j> is a sum over columns -- so a rank that owns the columns [c0, c1)
+// computes those columns of every P_k and At_k and its share of every inner product: all three GEMMs shard, no
 // intermediate is exchanged, and the ranks' partial Schur matrices are added by one all-reduce (nvar^2 doubles).
-// Every rank gets one contiguous range of tiles, chosen to minimise the largest load; work of tile t per constraint:
-// GEMM1' (nt-t) tiles of K = m-128t, GEMM2' tiles (i>=t) of K = m-128i, GEMM3' nd/2 x its packed length.
-static std::vector<std::pair<int, int>> col_tile_runs(int m, int nd, int rank, int world) {
-  const int nt = (m + 127) / 128, S = packed_S(m);
-  std::vector<std::pair<int, int>> runs;
-  if (world <= 1) { runs.push_back({0, nt}); return runs; }
-  std::vector<double> cost(nt);
-  for (int t = 0; t < nt; ++t) {
-    double k1 = (double)(nt - t) * (m - 128.0 * t), k2 = 0.0;
-    for (int i = t; i < nt; ++i) k2 += m - 128.0 * i;
-    const int c0 = 128 * t, c1 = std::min(m, c0 + 128);
-    const double k3 = (double)(16 * (c1 - c0)) + (double)(packed_off_base(c1, S) - packed_off_base(c0, S));
-    cost[t] = (k1 + k2) * 32768.0 + 0.5 * (double)nd * k3 * 2.0;
+// Every rank gets ONE contiguous column range whose ends are multiples of 16 (the block width of the packed layout):
+// the products of a range run on the trailing blocks A[c0:, c0:], L[c0:, c0:] with the 128-tile grid anchored at
+// c0, so a range costs whole tiles in GEMM1'/GEMM2' (its last tile column may be partly empty) and exactly its
+// packed length in GEMM3'.  col_range_cost prices that; a dynamic programme over the 16-column units minimises the
+// largest load (ties keep the smallest cut).  Python specification: sharding.column_range.
+//   GEMM1'  tile column j (K from its origin): (ntm - j) tiles x (M - 128 j) K
+//   GEMM2'  tile (i, j), i >= j (K from the row origin): M - 128 i
+//   GEMM3'  nd/2 pairs per constraint x 2 flop x packed length of the range
+// weighted by the rates the three kernels sustain at C4 (69 / 64 / 65 TFLOP/s on these counts, profiles/r01).
+static double col_range_cost(int m, int nd, int c0, int c1, int S) {
+  const double M = m - c0;
+  const int ntm = (m - c0 + 127) / 128, ntn = (c1 - c0 + 127) / 128;
+  double k1 = 0.0, k2 = 0.0;
+  for (int j = 0; j < ntn; ++j) {
+    k1 += (double)(ntm - j) * (M - 128.0 * j);
+    // sum_{i=j}^{ntm-1} (M - 128 i)
+    k2 += (double)(ntm - j) * M - 128.0 * (0.5 * (double)(ntm - 1) * ntm - 0.5 * (double)(j - 1) * j);
   }
-  // contiguous ranges (one run per rank: one launch per GEMM and batch) minimising the largest load:
-  // dp[p][j] = best largest load of the first j tiles over p ranks; ties keep the smallest cut
-  const int P = std::min(world, nt);
-  std::vector<double> pre(nt + 1, 0.0);
-  for (int t = 0; t < nt; ++t) pre[t + 1] = pre[t] + cost[t];
-  std::vector<std::vector<double>> dp(P + 1, std::vector<double>(nt + 1, 1e300));
-  std::vector<std::vector<int>> cut(P + 1, std::vector<int>(nt + 1, 0));
+  const double k3 = 16.0 * (c1 - c0) + (double)(packed_off_base(c1, S) - packed_off_base(c0, S));
+  return (k1 * 32768.0) / 69.0 + (k2 * 32768.0) / 64.0 + ((double)nd * k3) / 65.0;
+}
+
+static std::vector<std::pair<int, int>> col_runs(int m, int nd, int rank, int world) {
+  const int S = packed_S(m), nu = S / 16;          // 16-column units
+  std::vector<std::pair<int, int>> runs;
+  if (world <= 1) { runs.push_back({0, m}); return runs; }
+  auto col = [&](int u) { return std::min(m, 16 * u); };
+  const int P = std::min(world, nu);
+  // dp[p][j] = best largest load of the first j units over p ranks
+  std::vector<std::vector<double>> dp(P + 1, std::vector<double>(nu + 1, 1e300));
+  std::vector<std::vector<int>> cut(P + 1, std::vector<int>(nu + 1, 0));
   dp[0][0] = 0.0;
   for (int p = 1; p <= P; ++p)
-    for (int j = p; j <= nt; ++j)
+    for (int j = p; j <= nu; ++j)
       for (int i = p - 1; i < j; ++i) {
-        const double seg = pre[j] - pre[i];
+        if (dp[p - 1][i] >= dp[p][j]) continue;                    // cannot improve on the best found so far
+        const double seg = col_range_cost(m, nd, col(i), col(j), S);
         const double v = dp[p - 1][i] > seg ? dp[p - 1][i] : seg;
         if (v < dp[p][j]) { dp[p][j] = v; cut[p][j] = i; }
       }
   std::vector<int> lo(P), hi(P);
-  for (int p = P, j = nt; p >= 1; --p) { lo[p - 1] = cut[p][j]; hi[p - 1] = j; j = cut[p][j]; }
-  if (rank < P) runs.push_back({lo[rank], hi[rank]});
+  for (int p = P, j = nu; p >= 1; --p) { lo[p - 1] = cut[p][j]; hi[p - 1] = j; j = cut[p][j]; }
+  if (rank < P) runs.push_back({col(lo[rank]), col(hi[rank])});
   return runs;
 }
 
@@ -353,22 +355,41 @@ static long tri_p_batch(int m) {
 }
 
 static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
-  if (opt_schur_chol == 0) return false;
+  if (c->opt.schur_chol == 0) return false;
   if (b.npos_nz != b.nd || b.nd < 2 || b.msz < 2) return false;   // sparse partners gather from T_k = W A_k W itself
-  if (opt_schur_chol < 0 && b.msz < 256) return false;
+  if (c->opt.schur_chol < 0 && b.msz < 256) return false;
   if (c->world > 1 && !c->pos_space) return false;
-  // the column split deals 128-column tiles: with fewer tiles than ranks the Schur column blocks (all ranks busy) win
-  if (c->world > 1 && opt_schur_chol < 0 && (b.msz + 127) / 128 < c->world) return false;
+  // the column split deals 16-column units, whole 128-tiles at a time in GEMM1'/2': with fewer tiles than ranks the
+  // Schur column blocks (all ranks busy on full tiles) win
+  if (c->world > 1 && c->opt.schur_chol < 0 && (b.msz + 127) / 128 < c->world) return false;
+  // multi-GPU: the ranks must enter the same collective.  Everything above is the same on every rank; the memory
+  // test below is not (allocator state differs), so the host all-reduces lrn_schur_plan over the ranks and pins
+  // the result with option "schur_plan" (sharding.SchurExchange) -- a pinned plan is not re-decided here.
+  if (c->world > 1 && c->opt.schur_plan == 0) return false;
   const long mm = (long)b.msz * b.msz;
-  long pcap = opt_p_batch > 0 ? opt_p_batch : tri_p_batch(b.msz);
+  long pcap = c->opt.p_batch > 0 ? c->opt.p_batch : tri_p_batch(b.msz);
   if (pcap > b.nd) pcap = b.nd;
+  *pcap_out = pcap;
+  if (c->world > 1 && c->opt.schur_plan == 1) return true;        // (an allocation failure is then a loud error)
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
   double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes) * 0.92;
   double need = (double)b.nd * packed_total_elems(b.msz) * 8.0 + (double)pcap * mm * 8.0 + 10.0e9;   // + split-K slabs
   if (need > avail) return false;
-  *pcap_out = pcap;
   return true;
+}
+
+// lrn_schur_plan: 1 = the next assembly of this rank would take the Cholesky path (partial sums, all-reduce),
+// 0 = Schur column blocks (all-gather) -- from this rank's own view
+int schur_plan(lrn_ctx* c, int mode) {
+  if (mode == -1 || c->nlmi != 1) return 0;
+  LmiBlock& b = c->lmi[0];
+  long pcap = 0;
+  const int pin = c->opt.schur_plan;
+  c->opt.schur_plan = -1;                      // this rank's own view, whatever was pinned before
+  const bool ok = b.nd > 0 && c->opt.schur_chol != 2 && chol_path_applicable(c, b, &pcap);
+  c->opt.schur_plan = pin;
+  return ok ? 1 : 0;
 }
 
 // W = L L' for the assembly: c->wchol = [ L (col-major, strict upper part zeroed) | Ut = L' with explicit zeros |
@@ -429,15 +450,15 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   double* Ad = b.Adense.as<double>();
   double* P = c->P.as<double>();
   double* T = c->T.as<double>();
-  // ---- this rank's columns of the matrix variable (all of them on one GPU): runs of 128-column tiles
-  const std::vector<std::pair<int, int>> runs = col_tile_runs(m, nd, c->rank, c->world);
+  // ---- this rank's columns of the matrix variable (all of them on one GPU): [c0, c1), multiples of 16
+  const std::vector<std::pair<int, int>> runs = col_runs(m, nd, c->rank, c->world);
   const int S = packed_S(m);
   for (int a = 0; a < nd; a += (int)P_cap) {
     const int nb = std::min((int)P_cap, nd - a);
     for (auto& rn : runs) {
       // columns [c0, c1): P[c0:, c0:c1] = A[c0:, c0:] L[c0:, c0:c1] and At[c0:, c0:c1] = L[c0:, c0:]' P[c0:, c0:c1] are
       // the same triangular products on the trailing blocks (L lower triangular: nothing above row c0 contributes)
-      const int c0 = 128 * rn.first, c1 = std::min(m, 128 * rn.second);
+      const int c0 = rn.first, c1 = rn.second;
       const long off = (long)c0 + (long)c0 * m;
       tic(c);
       GemmDesc g1;   // P = A_a L, row-major (P[i][j] at j + i*m), tiles i >= j, K from the tile's column origin
@@ -483,22 +504,21 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     std::vector<RunK> rk;
     long chunks_all = 0;
     for (auto& rn : runs) {
-      const int c0 = 128 * rn.first, c1 = std::min(m, 128 * rn.second);
+      const int c0 = rn.first, c1 = rn.second;
       RunK r{c0, c1, (Kd + packed_off_base(c0, S)) / 16, (Kd + packed_off_base(c1, S)) / 16, 0, 0};
       chunks_all += (r.d1 - r.d0) + (r.o1 - r.o0);
       rk.push_back(r);
     }
-    {   // this rank's share of the three GEMMs (bench.py prices the roofline with them; 1 on one GPU)
-      const int nt = (m + 127) / 128;
-      double k1a = 0, k2a = 0, k1o = 0, k2o = 0;
-      for (int t = 0; t < nt; ++t) {
-        double k1 = (double)(nt - t) * (m - 128.0 * t), k2 = 0.0;
-        for (int i = t; i < nt; ++i) k2 += m - 128.0 * i;
-        k1a += k1; k2a += k2;
-        for (auto& rn : runs) if (t >= rn.first && t < rn.second) { k1o += k1; k2o += k2; }
+    {   // this rank's share of the USEFUL work of the three GEMMs (bench.py prices the roofline with them; 1 on one
+        // GPU): column c of P_k costs 2 (m - c)^2 flop and column c of At_k (m - c)^2, GEMM3' its packed length
+      double all = 0.0, own = 0.0;
+      for (int cc = 0; cc < m; ++cc) {
+        const double w = (double)(m - cc) * (m - cc);
+        all += w;
+        for (auto& rn : runs) if (cc >= rn.first && cc < rn.second) own += w;
       }
-      c->timing["gemm1_share"] = k1o / k1a;
-      c->timing["gemm2_share"] = k2o / k2a;
+      c->timing["gemm1_share"] = own / all;
+      c->timing["gemm2_share"] = own / all;
       c->timing["gemm3_share"] = (double)chunks_all / (double)(Kp / 16);
     }
     // split-K: short workgroups fill the workgroup slots evenly -- measured at C4: GEMM3' 548 / 524 / 509 / 505 ms
@@ -509,7 +529,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       if (chunks_all / k < 256 || (double)k * M * N * 8.0 > 9.0e9) continue;
       if (fill_eff(tiles * k) >= 0.97) { ksplit = k; break; }
     }
-    if (opt_gemm3_ksplit > 0) ksplit = std::min(64, opt_gemm3_ksplit);
+    if (c->opt.gemm3_ksplit > 0) ksplit = std::min(64, c->opt.gemm3_ksplit);
     // the splits of all runs go into ONE launch: split s walks chunks [kb[s], ke[s]) with slab weight 1 (diagonal
     // 16-blocks) or 2 (strictly-lower blocks)
     SlabWeights sw;
@@ -556,7 +576,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT;
       g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = 1;
       g3.kflat_kb = kb.data(); g3.kflat_ke = ke.data();
-      g3.kstagger = opt_gemm3_stagger;
+      g3.kstagger = c->opt.gemm3_stagger;
       g3.ksplit = nslab; g3.sCs = (long)M * N;
       LRN_TRY(gemm(c->stream, g3));
       toc(c, "gemm3");
@@ -584,8 +604,8 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   bool via_l = false;
   {
     long pcap = 0;
-    const bool want_chol = opt_schur_chol != 2 && chol_path_applicable(c, b, &pcap);
-    const bool want_via_l = opt_schur_chol > 0 || (opt_schur_chol < 0 && m >= 256);
+    const bool want_chol = c->opt.schur_chol != 2 && chol_path_applicable(c, b, &pcap);
+    const bool want_via_l = c->opt.schur_chol > 0 || (c->opt.schur_chol < 0 && m >= 256);
     if (want_chol || want_via_l) LRN_TRY(factor_w(c, b, &via_l));
     if (via_l && want_chol) return assemble_dense_chol(c, b, pcap);
   }
@@ -597,13 +617,13 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   if (b.t_cap == 0 || b.p_cap == 0) {
     size_t free_b = 0, total_b = 0;
     LRN_HIP(c, hipMemGetInfo(&free_b, &total_b));
-    long pcap = opt_p_batch > 0 ? opt_p_batch : (via_l ? tri_p_batch(m) : pick_p_batch(m, nd));
+    long pcap = c->opt.p_batch > 0 ? c->opt.p_batch : (via_l ? tri_p_batch(m) : pick_p_batch(m, nd));
     if (pcap > nd) pcap = nd;
     // memory that is free now plus what the shared workspaces already hold
     double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes + (double)c->P2.bytes) * 0.80 -
                    2.0 * (double)pcap * mm * 8.0 - 1.5e9;
     long tcap = (long)(avail / ((double)mm * 8.0));
-    if (opt_t_batch > 0) tcap = opt_t_batch;
+    if (c->opt.t_batch > 0) tcap = c->opt.t_batch;
     if (tcap > nd) tcap = nd;
     if (tcap < 1) return set_error(c, LRN_ERR_NOMEM, "not enough device memory for the T workspace");
     b.p_cap = pcap;
@@ -719,7 +739,7 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
         if ((long)m * m / 2 / BK_CHUNK / k < 1024 || (double)k * M * N * 8.0 > 9.0e9) continue;
         if (fill_eff(tiles * k) >= 0.97) { ksplit = k; break; }
       }
-      if (opt_gemm3_ksplit > 0) ksplit = std::min(64, opt_gemm3_ksplit);
+      if (c->opt.gemm3_ksplit > 0) ksplit = std::min(64, c->opt.gemm3_ksplit);
       size_t slab_bytes = (size_t)ksplit * M * N * 8;
       LRN_TRY(ensure(c, c->slabs, slab_bytes));
       GemmDesc g3;
@@ -899,7 +919,7 @@ int schur_factor(lrn_ctx* c, int* info) {
   // lrn_schur_add_diag) only the strict factorisation is used, as there.
   LRN_TRY(ensure(c, c->hdiag, (size_t)n * 8));
   int h_two[2] = {0, 0};
-  const bool try_boost = opt_pivot_boost > 0.0 && !c->H_shifted;
+  const bool try_boost = c->opt.pivot_boost > 0.0 && !c->H_shifted;
   for (int attempt = try_boost ? 0 : 1; attempt < 2; ++attempt) {
     LRN_HIP(c, hipMemcpyAsync(c->L.p, c->H.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 8, c->stream));
@@ -907,7 +927,7 @@ int schur_factor(lrn_ctx* c, int* info) {
       hipLaunchKernelGGL(get_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->H.as<double>(), n,
                          c->hdiag.as<double>());
     LRN_TRY(potrf_lower_boost(c->stream, c->L.as<double>(), n, n, c->Linv.as<double>(), c->cholwork.as<double>(),
-                              c->info_dev.as<int>(), attempt == 0 ? c->hdiag.as<double>() : nullptr, opt_pivot_boost,
+                              c->info_dev.as<int>(), attempt == 0 ? c->hdiag.as<double>() : nullptr, c->opt.pivot_boost,
                               std::max(8, n / 64)));
     LRN_HIP(c, hipMemcpyAsync(h_two, c->info_dev.p, 8, hipMemcpyDeviceToHost, c->stream));
     LRN_HIP(c, hipStreamSynchronize(c->stream));

@@ -24,10 +24,6 @@
 
 namespace lrn {
 
-int opt_svd_sdc = 0;             // 0 off, 1 on for msz >= opt_sdc_min
-int opt_sdc_min = 4000;
-int opt_sdc_leaf = 768;
-double opt_sdc_l0 = 1e-6;        // assumed lower bound of |lambda - sigma| / ||K - sigma I||_1
 
 namespace {
 
@@ -269,7 +265,7 @@ int leaf_jacobi(lrn_ctx* c, double* K, int n, double* V, const Work& w) {
 // K (n x n symmetric, destroyed) -> V (n x n, orthogonal, approximately diagonalising K)
 int sdc_rec(lrn_ctx* c, double* K, int n, double* V, Bump& bump, const Work& w, int depth) {
   hipStream_t st = c->stream;
-  if (n <= opt_sdc_leaf || depth >= 8) return leaf_jacobi(c, K, n, V, w);
+  if (n <= c->opt.sdc_leaf || depth >= 8) return leaf_jacobi(c, K, n, V, w);
   const size_t mark = bump.off;
   const long nn = (long)n * n;
   // shift: median of the diagonal; scale: 1-norm bound of K - sigma I
@@ -311,7 +307,7 @@ int sdc_rec(lrn_ctx* c, double* K, int n, double* V, Bump& bump, const Work& w, 
   hipLaunchKernelGGL(k_shift_scale, dim3(nbl(nn)), dim3(256), 0, st, K, n, sigma, 1.0 / alpha, X);
   int its = 0;
   bool ok = false;
-  LRN_TRY(qdwh_sign(c, X, n, Z, Y, w, &its, &ok, opt_sdc_l0, 12));
+  LRN_TRY(qdwh_sign(c, X, n, Z, Y, w, &its, &ok, c->opt.sdc_l0, 12));
   double tr = 0.0;
   int k = 0;
   for (int extra = 0; ok; ++extra) {

@@ -176,6 +176,13 @@ class Device:
         the Cholesky factor, world > 1): the exchange is then an all-reduce of `schur_export_full`."""
         return bool(self.lib.lrn_schur_is_partial_sum(self.h))
 
+    def schur_plan(self, mode=0):
+        """This rank's own view of the exchange the next assembly needs: 1 all-reduce of partial sums, 0 all-gather
+        of Schur column blocks (lrn_schur_plan; the ranks agree on MIN and pin it with option "schur_plan")."""
+        v = C.c_int(0)
+        self._chk(self.lib.lrn_schur_plan(self.h, int(mode), C.byref(v)), "lrn_schur_plan")
+        return int(v.value)
+
     def schur_export_full(self, buf):
         self._chk(self.lib.lrn_schur_export_full(self.h, ptr(buf)), "lrn_schur_export_full")
 

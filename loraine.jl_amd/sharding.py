@@ -79,68 +79,106 @@ def unpack_all(buf_all, nvar, world, bs=SHARD_BS):
 
 
 # ------------------------------------------------------------------ kit = 0, dense data: column split of the matrix variable
-def column_tiles(msz, nd, rank, world):
-    """Executable specification of `col_tile_runs` (csrc/schur.hip): the 128-column tiles of the matrix variable a
-    rank owns on the Cholesky path.  With W = L L', column c of At_k = L' A_k L needs only columns >= c of L and A_k
-    and <At_i, At_j> is a sum over columns, so a rank computes ITS columns of every At_k and its share of every inner
-    product; the ranks' partial Schur matrices are added by one all-reduce.  Every rank gets one contiguous range of
-    tiles, chosen to minimise the largest load (dynamic programme, ties keep the smallest cut)."""
-    nt = (msz + 127) // 128
-    if world <= 1:
-        return list(range(nt))
+def _packed_off_base(c, S):
+    q = c >> 4
+    return 16 * (q * S - 8 * q * (q + 1)) + (c - 16 * q) * (S - 16 * (q + 1))
+
+
+def column_range_cost(msz, nd, c0, c1):
+    """`col_range_cost` of csrc/schur.hip: what the columns [c0, c1) of the matrix variable cost a rank on the Cholesky
+    path.  The products run on the trailing blocks with the 128-tile grid anchored at c0: GEMM1' tile column j has
+    (ntm - j) tiles of K = M - 128 j, GEMM2' tile (i, j), i >= j, has K = M - 128 i (whole tiles, the last tile column
+    may be partly empty); GEMM3' costs exactly the packed length of the range, nd/2 pairs per constraint.  Weighted by
+    the rates the three kernels sustain (69 / 64 / 65 TFLOP/s on these counts)."""
     S = (msz + 15) // 16 * 16
+    M = float(msz - c0)
+    ntm, ntn = (msz - c0 + 127) // 128, (c1 - c0 + 127) // 128
+    k1 = k2 = 0.0
+    for j in range(ntn):
+        k1 += float(ntm - j) * (M - 128.0 * j)
+        k2 += float(ntm - j) * M - 128.0 * (0.5 * float(ntm - 1) * ntm - 0.5 * float(j - 1) * j)
+    k3 = 16.0 * (c1 - c0) + float(_packed_off_base(c1, S) - _packed_off_base(c0, S))
+    return (k1 * 32768.0) / 69.0 + (k2 * 32768.0) / 64.0 + (float(nd) * k3) / 65.0
 
-    def off_base(c):
-        q = c >> 4
-        return 16 * (q * S - 8 * q * (q + 1)) + (c - 16 * q) * (S - 16 * (q + 1))
 
-    cost = []
-    for t in range(nt):
-        k1 = (nt - t) * (msz - 128.0 * t)
-        k2 = sum(msz - 128.0 * i for i in range(t, nt))
-        c0, c1 = 128 * t, min(msz, 128 * t + 128)
-        k3 = 16.0 * (c1 - c0) + (off_base(c1) - off_base(c0))
-        cost.append((k1 + k2) * 32768.0 + 0.5 * nd * k3 * 2.0)
-    P = min(world, nt)
-    pre = [0.0]
-    for t in range(nt):
-        pre.append(pre[-1] + cost[t])
+def column_range(msz, nd, rank, world):
+    """Executable specification of `col_runs` (csrc/schur.hip): the columns [c0, c1) of the matrix variable a rank owns
+    on the Cholesky path, or None for a rank left idle (more ranks than 16-column units).  With W = L L', column c of
+    At_k = L' A_k L needs only columns >= c of L and A_k and <At_i, At_j> is a sum over columns, so a rank computes ITS
+    columns of every At_k and its share of every inner product; the ranks' partial Schur matrices are added by one
+    all-reduce.  Every rank gets one contiguous range with ends at multiples of 16 (the block width of the packed
+    layout), chosen by a dynamic programme over the 16-column units to minimise the largest `column_range_cost`
+    (ties keep the smallest cut)."""
+    if world <= 1:
+        return (0, msz)
+    nu = (msz + 15) // 16
+
+    def col(u):
+        return min(msz, 16 * u)
+
+    P = min(world, nu)
     INF = 1e300
-    dp = [[INF] * (nt + 1) for _ in range(P + 1)]
-    cut = [[0] * (nt + 1) for _ in range(P + 1)]
+    dp = [[INF] * (nu + 1) for _ in range(P + 1)]
+    cut = [[0] * (nu + 1) for _ in range(P + 1)]
     dp[0][0] = 0.0
     for p in range(1, P + 1):
-        for j in range(p, nt + 1):
+        for j in range(p, nu + 1):
             for i in range(p - 1, j):
-                seg = pre[j] - pre[i]
+                if dp[p - 1][i] >= dp[p][j]:
+                    continue
+                seg = column_range_cost(msz, nd, col(i), col(j))
                 v = dp[p - 1][i] if dp[p - 1][i] > seg else seg
                 if v < dp[p][j]:
                     dp[p][j], cut[p][j] = v, i
-    lo, hi, j = [0] * P, [0] * P, nt
+    lo, hi, j = [0] * P, [0] * P, nu
     for p in range(P, 0, -1):
         lo[p - 1], hi[p - 1] = cut[p][j], j
         j = cut[p][j]
-    return list(range(lo[rank], hi[rank])) if rank < P else []
+    return (col(lo[rank]), col(hi[rank])) if rank < P else None
 
 
-def partial_schur_dense(Amats, W, rank, world):
-    """NumPy restatement of one rank's partial sum on the Cholesky path (tests): H_g[i,j] = sum over the rank's
-    columns c of <At_i[:,c], At_j[:,c]>, At_k = L' A_k L."""
-    L = np.linalg.cholesky(W)
-    msz = W.shape[0]
-    cols = np.concatenate([np.arange(128 * t, min(msz, 128 * t + 128)) for t in column_tiles(msz, len(Amats), rank, world)]
-                          or [np.zeros(0, dtype=int)]).astype(int)
-    At = np.stack([(L.T @ a @ L)[:, cols] for a in Amats]).reshape(len(Amats), -1)
-    return At @ At.T
+def agree_on_plan(dev, group=None, mode=0):
+    """Every rank must enter the same collective after the assembly.  The choice between the two exchanges depends on
+    free device memory, which differs between ranks: all-reduce (MIN) each rank's own `lrn_schur_plan` and pin the
+    result on every rank (option "schur_plan").  Returns the agreed plan (1 all-reduce of partial sums, 0 all-gather
+    of column blocks)."""
+    import torch
+    import torch.distributed as dist
+    mine = dev.schur_plan(mode)
+    on_gpu = dist.get_backend(group) != "gloo"
+    t = torch.tensor([mine], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    plan = int(t.item())
+    dev.set_option("schur_plan", plan)
+    return plan
+
+
+def check_same_exchange(dev, group=None):
+    """After the assembly: all ranks hold the same kind of result (partial sums or column blocks)?  One tiny
+    all-reduce that every rank enters unconditionally; a disagreement (a rank whose W could not be factored, a
+    plan that was not pinned) raises on every rank instead of pairing an all-reduce with an all-gather."""
+    import torch
+    import torch.distributed as dist
+    f = 1 if dev.schur_is_partial_sum() else 0
+    on_gpu = dist.get_backend(group) != "gloo"
+    t = torch.tensor([f, -f], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0].item()), -int(t[1].item())
+    if hi != lo:
+        raise RuntimeError("ranks disagree on the Schur exchange (partial sums on some, column blocks on others): "
+                           "refusing to enter mismatched collectives")
+    return bool(hi)
 
 
 class SchurExchange:
     """The collective step of the sharded direct solve (product path, GPU tensors)."""
 
-    def __init__(self, dev, rank, world, group=None):
+    def __init__(self, dev, rank, world, group=None, mode=0):
         import torch
         self.dev, self.rank, self.world, self.group = dev, rank, world, group
         dev.set_shard(rank, world)
+        # construct BEFORE the first sharded assembly: the plan the ranks agree on here decides its path
+        self.plan = agree_on_plan(dev, group, mode) if world > 1 else 0
         n = dev.shard_doubles()
         self.shard = torch.zeros(n, dtype=torch.float64, device="cuda")
         self.gathered = torch.zeros(n * world, dtype=torch.float64, device="cuda")
@@ -168,7 +206,8 @@ class SchurExchange:
         import torch
         import torch.distributed as dist
         self.dev.set_shard(self.rank, self.world)
-        if self.dev.schur_is_partial_sum():
+        partial = check_same_exchange(self.dev, self.group) if self.world > 1 else self.dev.schur_is_partial_sum()
+        if partial:
             return self.allreduce_full()
         self.dev.schur_export_shard(self.shard)
         if dist.get_backend(self.group) == "gloo":        # rehearsal on a one-GPU box: stage through the host
@@ -278,6 +317,10 @@ class DistributedHotPath:
         self.shard_schur = self.world > 1 and (solver.kit == 1 or solver.model.nlmi == 1)
         if self.shard_schur:
             solver.dev.set_shard(self.rank, self.world)     # assembly from now on covers the owned column blocks
+            if solver.kit == 0:
+                # the ranks agree on the exchange BEFORE the first assembly (SchurExchange pins the plan)
+                self._exchange = SchurExchange(solver.dev, self.rank, self.world, self.group,
+                                               mode=-1 if getattr(solver, "datarank", 0) == -1 else 0)
         else:
             solver.dev.set_shard(0, 1)
 

@@ -377,9 +377,10 @@ def test_chol_path_two_blocks_and_switching(dev):
 
 @pytest.mark.parametrize("msz,nvar,world", [(260, 300, 2), (260, 300, 3), (260, 300, 5), (1000, 160, 3), (1000, 160, 8)])
 def test_chol_path_column_split_partial_sums(dev, msz, nvar, world):
-    """world > 1 on the Cholesky path: the ranks split the 128-column tiles of the matrix variable (all three GEMMs
-    shard) and hold partial sums of the whole Schur matrix; their sum (the all-reduce) is the one-rank matrix.  Also
-    more ranks than tiles (idle ranks contribute zero), and the tile dealing equals its Python specification."""
+    """world > 1 on the Cholesky path: the ranks split the columns of the matrix variable in 16-column units (all
+    three GEMMs shard, tile grids anchored at the range start) and hold partial sums of the whole Schur matrix;
+    their sum (the all-reduce) is the one-rank matrix.  Also more ranks than units (idle ranks contribute zero), and
+    the dealing equals its Python specification."""
     import torch
     from loraine_jl_amd import sharding
     dev.synthetic_dense_model(msz, nvar, 11)
@@ -397,8 +398,8 @@ def test_chol_path_column_split_partial_sums(dev, msz, nvar, world):
             dev.reset_timing()
             dev.schur_assemble(0)
             assert dev.count("schur_chol") == 1 and dev.schur_is_partial_sum()
-            tiles = sharding.column_tiles(msz, nvar, r, world)
-            assert (dev.timing("gemm3_share") > 0) == (len(tiles) > 0)
+            cols = sharding.column_range(msz, nvar, r, world)
+            assert (dev.timing("gemm3_share") > 0) == (cols is not None)
             shares += dev.timing("gemm3_share")
             dev.schur_export_full(buf)
             torch.cuda.synchronize()

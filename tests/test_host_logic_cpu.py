@@ -93,3 +93,37 @@ def test_lowrank_generator_is_consistent():
         assert np.array_equal(Mk, Mk.T) and abs(np.trace(Mk)) < 1e-14 and np.count_nonzero(Mk) == 9
     m = P.model()
     assert m.n == 90 and m.nlmi == 1 and m.nlin == 0 and int(m.qA[0, 0]) == 90
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no torchrun environment) must start N ranks itself, before anything
+    touches a GPU, and exit with their code; a WORLD_SIZE that contradicts --gpus is an error."""
+    import subprocess
+    import sys
+    import bench
+    calls = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        calls["cmd"], calls["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    monkeypatch.setitem(sys.modules, "torch", None)          # the launcher must not need torch: import would fail
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                  # the ranks' exit code is the launcher's
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher with another world size: refuse
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)

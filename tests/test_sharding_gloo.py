@@ -133,13 +133,24 @@ def test_world2_gloo_sharded_pcg(tmp_path):
     assert np.load(tmp_path / "cg.npy")[0] == 2.0
 
 
+def partial_schur_dense(Amats, W, rank, world):
+    """NumPy restatement of one rank's partial sum on the Cholesky path: H_g[i,j] = sum over the rank's columns c of
+    <At_i[:,c], At_j[:,c]>, At_k = L' A_k L (csrc/schur.hip::assemble_dense_chol)."""
+    from loraine_jl_amd import sharding
+    L = np.linalg.cholesky(W)
+    rng_ = sharding.column_range(W.shape[0], len(Amats), rank, world)
+    cols = np.arange(*rng_) if rng_ else np.zeros(0, dtype=int)
+    At = np.stack([(L.T @ a @ L)[:, cols] for a in Amats]).reshape(len(Amats), -1)
+    return At @ At.T
+
+
 def _worker_colsplit(rank, world, port, out_dir):
     import loraine_jl_amd  # noqa: F401
     from loraine_jl_amd import sharding
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    msz, nvar = 300, 12                                  # three 128-column tiles
+    msz, nvar = 300, 12                                  # nineteen 16-column units
     rng = np.random.default_rng(5)
     A = []
     for _ in range(nvar):
@@ -147,13 +158,13 @@ def _worker_colsplit(rank, world, port, out_dir):
         A.append((R + R.T) / 2)
     G = rng.standard_normal((msz, msz)) / np.sqrt(msz) + np.eye(msz)
     W = G @ G.T
-    part = torch.from_numpy(sharding.partial_schur_dense(A, W, rank, world))
+    part = torch.from_numpy(partial_schur_dense(A, W, rank, world))
     dist.all_reduce(part)                                # the only exchange of the dense direct path
     T = np.stack([W @ a @ W for a in A])
     Href = np.stack(A).reshape(nvar, -1) @ T.reshape(nvar, -1).T
     err = np.linalg.norm(part.numpy() - Href) / np.linalg.norm(Href)
-    mine = sharding.column_tiles(msz, nvar, rank, world)
-    res = torch.tensor([err, float(len(mine))], dtype=torch.float64)
+    mine = sharding.column_range(msz, nvar, rank, world)
+    res = torch.tensor([err, float(mine[1] - mine[0])], dtype=torch.float64)
     both = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, res)
     if rank == 0:
@@ -170,17 +181,85 @@ def test_world2_gloo_column_split_allreduce(tmp_path):
     mp.spawn(_worker_colsplit, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     res = np.load(tmp_path / "res_colsplit.npy")
     assert (res[:, 0] < 1e-12).all()
-    assert res[:, 1].sum() == 3                           # every tile owned exactly once
+    assert res[:, 1].sum() == 300                         # every column owned exactly once
 
 
-def test_column_tiles_partition_and_balance():
+def test_column_range_partition_and_balance():
     import loraine_jl_amd  # noqa: F401
     from loraine_jl_amd import sharding
-    for msz, world in [(2000, 1), (2000, 2), (2000, 4), (2000, 8), (300, 5), (128, 3)]:
-        nt = (msz + 127) // 128
-        owned = [sharding.column_tiles(msz, 4000, r, world) for r in range(world)]
-        assert sorted(t for o in owned for t in o) == list(range(nt))
-    # the metric configuration: contiguous ranges, the heaviest tile (columns 0..127) alone on rank 0 of 8
-    o8 = [sharding.column_tiles(2000, 4000, r, 8) for r in range(8)]
-    assert o8[0] == [0] and all(o == list(range(o[0], o[-1] + 1)) for o in o8)
-    assert [len(o) for o in [sharding.column_tiles(2000, 4000, r, 2) for r in range(2)]] == [4, 12]
+    for msz, world in [(2000, 1), (2000, 2), (2000, 4), (2000, 8), (300, 5), (128, 3), (40, 8), (1000, 6)]:
+        owned = [sharding.column_range(msz, 4000, r, world) for r in range(world)]
+        live = [o for o in owned if o is not None]
+        # contiguous, in rank order, ends at multiples of 16, every column exactly once
+        assert live[0][0] == 0 and live[-1][1] == msz
+        assert all(a[1] == b[0] for a, b in zip(live, live[1:]))
+        assert all(o[0] % 16 == 0 and (o[1] % 16 == 0 or o[1] == msz) and o[1] > o[0] for o in live)
+        assert len(live) == min(world, (msz + 15) // 16)
+    # the metric configuration on 8 ranks: the heaviest columns (0..127: the longest K ranges and the longest packed
+    # columns) no longer sit on one rank as a whole 128-tile -- the slowest rank is within 8 % of the mean
+    o8 = [sharding.column_range(2000, 4000, r, 8) for r in range(8)]
+    cost = [sharding.column_range_cost(2000, 4000, *o) for o in o8]
+    assert o8[0][1] < 128
+    assert max(cost) < 1.08 * (sum(cost) / 8)
+    # ... where whole 128-tiles (the round-1 split: {0} {1} {2} {3} {4} [5,7) [7,9) [9,16)) left it 28 % above
+    t8 = [(0, 128), (128, 256), (256, 384), (384, 512), (512, 640), (640, 896), (896, 1152), (1152, 2000)]
+    ct = [sharding.column_range_cost(2000, 4000, *o) for o in t8]
+    assert max(ct) > 1.2 * (sum(ct) / 8) and max(cost) < 0.95 * max(ct)
+
+
+class _FakeDev:
+    """What sharding.agree_on_plan / check_same_exchange need of a Device."""
+
+    def __init__(self, plan, partial):
+        self._plan, self._partial, self.options = plan, partial, {}
+
+    def schur_plan(self, mode=0):
+        return self._plan
+
+    def set_option(self, k, v):
+        self.options[k] = v
+
+    def schur_is_partial_sum(self):
+        return self._partial
+
+
+def _worker_plan(rank, world, port, out_dir):
+    import loraine_jl_amd  # noqa: F401
+    from loraine_jl_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    # rank 1 is short of memory and would fall back to the column blocks: both ranks must then take them
+    dev = _FakeDev(plan=1 if rank == 0 else 0, partial=False)
+    res.append(float(sharding.agree_on_plan(dev)))
+    res.append(float(dev.options["schur_plan"]))
+    # unanimous
+    dev = _FakeDev(plan=1, partial=True)
+    res.append(float(sharding.agree_on_plan(dev)))
+    res.append(float(sharding.check_same_exchange(dev)))
+    # a rank whose assembly ended on the other path (forced schur_chol = 0 on rank 1): every rank raises, none
+    # enters an all-reduce against an all-gather
+    dev = _FakeDev(plan=1, partial=(rank == 0))
+    try:
+        sharding.check_same_exchange(dev)
+        res.append(0.0)
+    except RuntimeError:
+        res.append(1.0)
+    out = [torch.zeros(5, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(out, torch.tensor(res, dtype=torch.float64))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "plan.npy"), np.stack([o.numpy() for o in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_ranks_agree_on_the_exchange(tmp_path):
+    """each rank used to choose its collective from its own free memory.  Now the plan is all-reduced
+    (MIN) and pinned before the first assembly, and a divergent outcome raises on every rank."""
+    port = _free_port()
+    mp.spawn(_worker_plan, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = np.load(tmp_path / "plan.npy")
+    assert (res[:, 0] == 0).all() and (res[:, 1] == 0).all()       # MIN of (1, 0), pinned on both ranks
+    assert (res[:, 2] == 1).all() and (res[:, 3] == 1).all()
+    assert (res[:, 4] == 1).all()                                    # both ranks raised
