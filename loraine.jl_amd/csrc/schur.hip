@@ -438,8 +438,21 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   const long cstride = 16L * nd;              // chunk-major: chunk q of At_k at q * cstride + 16 k
   const size_t t_bytes = (size_t)(Kp / 16) * cstride * 8;
   double* Ut = c->wchol.as<double>() + mm;
-  // ---- workspaces: P (batch of row-major A_k L), T (all At_k, packed)
-  LRN_TRY(ensure(c, c->P, (size_t)P_cap * mm * 8));
+  // ---- this rank's columns of the matrix variable (all of them on one GPU): [c0, c1), multiples of 16
+  const std::vector<std::pair<int, int>> runs = col_runs(m, nd, c->rank, c->world);
+  const int S = packed_S(m);
+  // ---- workspaces: P (batch of row-major blocks P_k[c0:, c0:c1] = A_k[c0:, c0:] L[c0:, c0:c1]), T (all At_k, packed).
+  // P holds only the owned columns (leading dimension = their count rounded to 16), so a rank with a narrow range
+  // takes many more matrices per launch: the triangular products end every launch with a drain of unequal
+  // workgroups, and 8 ranks would otherwise pay 16 of them on a fraction of the work.
+  long p_elems = 0;                       // doubles per matrix
+  for (auto& rn : runs) p_elems = std::max(p_elems, (long)(m - rn.first) * (((rn.second - rn.first) + 15) & ~15));
+  if (p_elems > 0) {
+    long cap = c->opt.p_batch > 0 ? c->opt.p_batch : std::max<long>(16, (long)(8.6e9 / ((double)p_elems * 8.0)));
+    if (c->opt.p_batch <= 0 && c->world <= 1) cap = std::min<long>(cap, 256);
+    P_cap = std::min<long>(std::min<long>(cap, nd), 32768);
+  }
+  LRN_TRY(ensure(c, c->P, (size_t)P_cap * std::max<long>(p_elems, 1) * 8));
   const void* t_before = c->T.p;
   LRN_TRY(ensure(c, c->T, t_bytes));                        // (a fresh allocation comes back zeroed)
   if (c->T.p == t_before && (c->T_layout != 1 || c->T_m != m || c->T_owner != &b))
@@ -450,9 +463,6 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   double* Ad = b.Adense.as<double>();
   double* P = c->P.as<double>();
   double* T = c->T.as<double>();
-  // ---- this rank's columns of the matrix variable (all of them on one GPU): [c0, c1), multiples of 16
-  const std::vector<std::pair<int, int>> runs = col_runs(m, nd, c->rank, c->world);
-  const int S = packed_S(m);
   for (int a = 0; a < nd; a += (int)P_cap) {
     const int nb = std::min((int)P_cap, nd - a);
     for (auto& rn : runs) {
@@ -460,11 +470,12 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       // the same triangular products on the trailing blocks (L lower triangular: nothing above row c0 contributes)
       const int c0 = rn.first, c1 = rn.second;
       const long off = (long)c0 + (long)c0 * m;
+      const long ldp = ((c1 - c0) + 15) & ~15;               // P block: (m - c0) rows x ldp, row-major
       tic(c);
-      GemmDesc g1;   // P = A_a L, row-major (P[i][j] at j + i*m), tiles i >= j, K from the tile's column origin
+      GemmDesc g1;   // P = A_a L, row-major (P[i][j] at j + i*ldp), tiles i >= j, K from the tile's column origin
       g1.A = Ad + (long)a * mm + off; g1.sAm = 1; g1.sAk = m; g1.bA = mm;
       g1.B = Ut + off; g1.sBk = m; g1.sBn = 1; g1.bB = 0;     // op(B)[k][j] = L[k,j] = Ut[j + k*m]
-      g1.C = P + off; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
+      g1.C = P; g1.sCm = ldp; g1.sCn = 1; g1.bC = p_elems;
       g1.M = g1.K = m - c0; g1.N = c1 - c0; g1.batch = nb;
       g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N;
       LRN_TRY(gemm(c->stream, g1));
@@ -472,7 +483,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       tic(c);
       GemmDesc g2;   // At = L' P, tiles i >= j, K from the tile's row origin, stored packed
       g2.A = Ut + off; g2.sAm = 1; g2.sAk = m; g2.bA = 0;     // op(A)[i][k] = L[k,i] = Ut[i + k*m]
-      g2.B = P + off; g2.sBk = m; g2.sBn = 1; g2.bB = mm;
+      g2.B = P; g2.sBk = ldp; g2.sBn = 1; g2.bB = p_elems;
       g2.C = T + (long)a * 16; g2.sCm = 1; g2.sCn = m; g2.bC = 16;
       g2.pk_cstride = cstride;
       g2.M = g2.K = m - c0; g2.N = c1 - c0; g2.batch = nb;

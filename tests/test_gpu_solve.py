@@ -105,8 +105,8 @@ def test_whole_solves_through_the_cholesky_factor_paths(name, opt, chol, residen
     import loraine_jl_amd
     path = os.path.join(GOLD, f"{name}.dat-s")
 
-    def run(**extra):
-        o = Optimizer(resident=resident)
+    def run(device=None, **extra):
+        o = Optimizer(resident=resident, device=device)
         o.set_silent(True)
         o.set_attribute("kit", 0)
         for k, v in extra.items():
@@ -116,16 +116,14 @@ def test_whole_solves_through_the_cholesky_factor_paths(name, opt, chol, residen
         return o
 
     base = run()
-    d = loraine_jl_amd.Device(0)
+    d = loraine_jl_amd.Device(0)                # options are per context: the solve runs on this one
     d.set_option("dense_threshold", 1)
     d.set_option("schur_chol", chol)
     try:
-        o = run(datasparsity=0)                 # every constraint takes branch 1 (makeBBBB.jl:81) -> the dense path
+        o = run(device=d, datasparsity=0)       # every constraint takes branch 1 (makeBBBB.jl:81) -> the dense path
         used = sum(t.get("schur_chol" if chol == 1 else "schur_via_l", 0) for t in o.solver.trace)
         fails = sum(t.get("wchol_fail", 0) for t in o.solver.trace)
     finally:
-        d.set_option("dense_threshold", -1)
-        d.set_option("schur_chol", -1)
         d.close()
     assert o.termination_status() == "OPTIMAL" and base.termination_status() == "OPTIMAL"
     assert o.objective_value() == pytest.approx(opt, rel=1e-6)

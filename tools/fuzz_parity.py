@@ -63,7 +63,8 @@ def main():
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     bad = 0
     t0 = time.time()
-    # library-wide options: FUZZ_SCHUR_CHOL=1 takes the Cholesky-factor assembly paths regardless of size
+    _d = None
+    # per-context options on the device every solve runs on: FUZZ_SCHUR_CHOL=1 takes the Cholesky-factor assembly paths regardless of size
     # (1: <L'A_iL, L'A_jL> where every constraint of a block is dense, T_k = L (L'A_kL) L' otherwise; 2: the latter
     # only), FUZZ_DENSE=1 stores every non-empty constraint matrix dense
     if os.environ.get("FUZZ_SCHUR_CHOL") or os.environ.get("FUZZ_DENSE"):
@@ -90,7 +91,7 @@ def main():
             except Exception as e:
                 rs, ro, ri = "exc:" + type(e).__name__, None, None
             for resident in (True, False):
-                o = Optimizer(resident=resident); o.set_silent(True)
+                o = Optimizer(resident=resident, device=_d); o.set_silent(True)
                 for k, v in opts.items(): o.set_attribute(k, v)
                 o.load_model([[m.copy() for m in blk] for blk in A], b.copy(), 0.0, d_lin, C_lin, max_sense=False)
                 try:
