@@ -303,23 +303,28 @@ __global__ void reduce_slabs_w_kernel(const double* __restrict__ slabs, long str
 // Every rank gets ONE contiguous column range whose ends are multiples of 16 (the block width of the packed layout):
 // the products of a range run on the trailing blocks A[c0:, c0:], L[c0:, c0:] with the 128-tile grid anchored at
 // c0, so a range costs whole tiles in GEMM1'/GEMM2' (its last tile column may be partly empty) and exactly its
-// packed length in GEMM3'.  col_range_cost prices that; a dynamic programme over the 16-column units minimises the
-// largest load (ties keep the smallest cut).  Python specification: sharding.column_range.
+// packed length in GEMM3'.  col_range_cost prices that (in ms); a dynamic programme over the 16-column units minimises
+// the largest load (ties keep the smallest cut).  Python specification: sharding.column_range.
 //   GEMM1'  tile column j (K from its origin): (ntm - j) tiles x (M - 128 j) K
 //   GEMM2'  tile (i, j), i >= j (K from the row origin): M - 128 i
-//   GEMM3'  nd/2 pairs per constraint x 2 flop x packed length of the range
-// weighted by the rates the three kernels sustain at C4 (69 / 64 / 65 TFLOP/s on these counts, profiles/r01).
+//   GEMM3'  nd^2 / 2 pairs x 2 flop x packed length of the range
+// The constants are a least-squares fit to the per-rank times of the C4 instance replayed on one GPU for 1, 2, 4 and
+// 8 ranks (tools/shard_balance.py, profiles/r02_shard_balance.txt; ms at nd = 4000): GEMM1'/GEMM2' cost a fixed
+// equivalent of ~220 K per tile on top of their K length (short tiles are dearer per flop; fit within 9 % / 17 %),
+// GEMM3' is linear in the packed length (within 0.8 %).
 static double col_range_cost(int m, int nd, int c0, int c1, int S) {
   const double M = m - c0;
   const int ntm = (m - c0 + 127) / 128, ntn = (c1 - c0 + 127) / 128;
-  double k1 = 0.0, k2 = 0.0;
+  double k1 = 0.0, k2 = 0.0, tiles = 0.0;
   for (int j = 0; j < ntn; ++j) {
     k1 += (double)(ntm - j) * (M - 128.0 * j);
     // sum_{i=j}^{ntm-1} (M - 128 i)
     k2 += (double)(ntm - j) * M - 128.0 * (0.5 * (double)(ntm - 1) * ntm - 0.5 * (double)(j - 1) * j);
+    tiles += (double)(ntm - j);
   }
   const double k3 = 16.0 * (c1 - c0) + (double)(packed_off_base(c1, S) - packed_off_base(c0, S));
-  return (k1 * 32768.0) / 69.0 + (k2 * 32768.0) / 64.0 + ((double)nd * k3) / 65.0;
+  const double s = (double)nd / 4000.0;
+  return s * (0.0016774 * (k1 + 219.0 * tiles) + 0.0016283 * (k2 + 228.0 * tiles)) + s * s * 0.00024209 * k3;
 }
 
 static std::vector<std::pair<int, int>> col_runs(int m, int nd, int rank, int world) {

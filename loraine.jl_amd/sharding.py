@@ -86,19 +86,22 @@ def _packed_off_base(c, S):
 
 def column_range_cost(msz, nd, c0, c1):
     """`col_range_cost` of csrc/schur.hip: what the columns [c0, c1) of the matrix variable cost a rank on the Cholesky
-    path.  The products run on the trailing blocks with the 128-tile grid anchored at c0: GEMM1' tile column j has
-    (ntm - j) tiles of K = M - 128 j, GEMM2' tile (i, j), i >= j, has K = M - 128 i (whole tiles, the last tile column
-    may be partly empty); GEMM3' costs exactly the packed length of the range, nd/2 pairs per constraint.  Weighted by
-    the rates the three kernels sustain (69 / 64 / 65 TFLOP/s on these counts)."""
+    path, in ms.  The products run on the trailing blocks with the 128-tile grid anchored at c0: GEMM1' tile column j
+    has (ntm - j) tiles of K = M - 128 j, GEMM2' tile (i, j), i >= j, has K = M - 128 i (whole tiles, the last tile
+    column may be partly empty); GEMM3' costs exactly the packed length of the range.  Constants: least-squares fit to
+    the per-rank times of the C4 instance replayed on one GPU (tools/shard_balance.py, profiles/r02_shard_balance.txt):
+    a fixed equivalent of ~220 K per tile in GEMM1'/GEMM2', GEMM3' linear in the packed length."""
     S = (msz + 15) // 16 * 16
     M = float(msz - c0)
     ntm, ntn = (msz - c0 + 127) // 128, (c1 - c0 + 127) // 128
-    k1 = k2 = 0.0
+    k1 = k2 = tiles = 0.0
     for j in range(ntn):
         k1 += float(ntm - j) * (M - 128.0 * j)
         k2 += float(ntm - j) * M - 128.0 * (0.5 * float(ntm - 1) * ntm - 0.5 * float(j - 1) * j)
+        tiles += float(ntm - j)
     k3 = 16.0 * (c1 - c0) + float(_packed_off_base(c1, S) - _packed_off_base(c0, S))
-    return (k1 * 32768.0) / 69.0 + (k2 * 32768.0) / 64.0 + (float(nd) * k3) / 65.0
+    s = float(nd) / 4000.0
+    return s * (0.0016774 * (k1 + 219.0 * tiles) + 0.0016283 * (k2 + 228.0 * tiles)) + s * s * 0.00024209 * k3
 
 
 def column_range(msz, nd, rank, world):

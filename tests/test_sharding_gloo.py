@@ -195,16 +195,13 @@ def test_column_range_partition_and_balance():
         assert all(a[1] == b[0] for a, b in zip(live, live[1:]))
         assert all(o[0] % 16 == 0 and (o[1] % 16 == 0 or o[1] == msz) and o[1] > o[0] for o in live)
         assert len(live) == min(world, (msz + 15) // 16)
-    # the metric configuration on 8 ranks: the heaviest columns (0..127: the longest K ranges and the longest packed
-    # columns) no longer sit on one rank as a whole 128-tile -- the slowest rank is within 8 % of the mean
-    o8 = [sharding.column_range(2000, 4000, r, 8) for r in range(8)]
-    cost = [sharding.column_range_cost(2000, 4000, *o) for o in o8]
-    assert o8[0][1] < 128
-    assert max(cost) < 1.08 * (sum(cost) / 8)
-    # ... where whole 128-tiles (the round-1 split: {0} {1} {2} {3} {4} [5,7) [7,9) [9,16)) left it 28 % above
-    t8 = [(0, 128), (128, 256), (256, 384), (384, 512), (512, 640), (640, 896), (896, 1152), (1152, 2000)]
-    ct = [sharding.column_range_cost(2000, 4000, *o) for o in t8]
-    assert max(ct) > 1.2 * (sum(ct) / 8) and max(cost) < 0.95 * max(ct)
+    # the metric configuration on 8 ranks (cost in ms, fitted to the replay in profiles/r02_shard_balance.txt): the
+    # slowest rank within 9 % of the mean; 2 and 4 ranks within 2 % / 7 %
+    for world, tol in ((2, 1.02), (4, 1.07), (8, 1.09)):
+        o = [sharding.column_range(2000, 4000, r, world) for r in range(world)]
+        cost = [sharding.column_range_cost(2000, 4000, *x) for x in o]
+        assert max(cost) < tol * (sum(cost) / world)
+    assert 1000 < sharding.column_range_cost(2000, 4000, 0, 2000) < 1100     # the one-GPU assembly, ms
 
 
 class _FakeDev:
