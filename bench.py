@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-msz", type=int, default=300)
     ap.add_argument("--cpu-nvar", type=int, default=400)
+    ap.add_argument("--cpu-msz2", type=int, default=500)        # SURVEY.md 8d's scaled instance (bounded sample)
+    ap.add_argument("--cpu-nvar2", type=int, default=1000)
+    ap.add_argument("--cpu-sample2", type=int, default=96)      # constraints of it timed on the CPU
     return ap.parse_args()
 
 
@@ -78,35 +81,45 @@ def make_scaling(msz, seed):
     return G @ G.T, G
 
 
-def cpu_baseline(msz, nvar, seed):
-    """The CPU restatement of the reference path (oracle, kind 'port') timed on the host cores
-    on a bounded sample of the same workload, plus the GPU path on the very same sample."""
+class _DenseRows:
+    """A[ilmi]-like view of dense constraint rows (index k >= 1 -> CSC of A_k), so that the oracle's makeBBBBsi can
+    be fed without the oracle's general (slow, per-entry) model builder."""
+
+    def __init__(self, rows, msz):
+        self.rows, self.msz = rows, msz
+
+    def __getitem__(self, k):
+        import scipy.sparse as sp
+        return sp.csc_matrix(self.rows[k - 1].reshape(self.msz, self.msz))
+
+
+def _dense_instance(msz, nvar, seed):
+    """Same generator as the metric config (A_k = (R + R')/2, R iid N(0,1)) in the oracle's model form: AA = -vec(A_k)
+    rows as CSR (src/model.jl:219-226), sigmaA = identity (all nnz equal: the stable nnz sort of src/model.jl:159
+    keeps the order), qA = nvar (every constraint takes branch 1, src/makeBBBB.jl:81)."""
     import numpy as np
     import scipy.sparse as sp
-    from oracle import loraine_oracle as lo
-    import loraine_jl_amd
     rng = np.random.default_rng(seed)
-    A = [[sp.csc_matrix((msz, msz))]]
-    for _ in range(nvar):
+    mm = msz * msz
+    rows = np.empty((nvar, mm))
+    for k in range(nvar):
         R = rng.standard_normal((msz, msz))
-        A[0].append(sp.csc_matrix((R + R.T) / 2))
-    model = lo.make_model(A, rng.standard_normal(nvar), 0.0, None, None)
-    W, G = make_scaling(msz, seed + 1)
-    h1, h2 = rng.standard_normal(nvar), rng.standard_normal(nvar)
-    import scipy.linalg as sla
-    t0 = time.perf_counter()
-    H = lo.makeBBBBs(model.n, 1, model.A, model.AA, [W], model.qA, model.sigmaA)
-    Hl = np.tril(H)
-    L = np.linalg.cholesky(Hl + np.tril(Hl, -1).T)
-    for h in (h1, h2):
-        x = sla.solve_triangular(L.T, sla.solve_triangular(L, h, lower=True), lower=False)
-    cpu_ms = (time.perf_counter() - t0) * 1e3
+        rows[k] = ((R + R.T) / 2).reshape(-1)
+    AA = sp.csr_matrix((-rows.reshape(-1), np.tile(np.arange(mm, dtype=np.int32), nvar),
+                        np.arange(nvar + 1, dtype=np.int64) * mm), shape=(nvar, mm))
+    sigmaA = np.arange(nvar, dtype=np.int64).reshape(nvar, 1)
+    qA = np.full((2, 1), nvar, dtype=np.int64)
+    return rows, AA, sigmaA, qA, rng
+
+
+def _gpu_same_sample(rows, AA, sigmaA, qA, msz, W, G, h1, h2):
+    import numpy as np
+    import torch
+    import loraine_jl_amd
     dev = loraine_jl_amd.Device(0)
     dev.set_option("dense_threshold", 1)
-    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
-    dev.set_option("dense_threshold", -1)
+    dev.upload_model([AA], sigmaA, qA, [msz])
     dev.set_scaling(0, W, G)
-    import torch
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -116,19 +129,83 @@ def cpu_baseline(msz, nvar, seed):
         xg = dev.schur_solve(h2)
         torch.cuda.synchronize()
         gpu_ms = (time.perf_counter() - t0) * 1e3
-    err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
     dev.close()
+    return gpu_ms, np.asarray(xg)
+
+
+def cpu_baseline(msz, nvar, seed, msz2=500, nvar2=1000, sample2=96):
+    """The CPU restatement of the reference path (oracle, kind 'port') timed on the host cores on bounded samples of
+    the same workload, with the GPU path on the very same inputs:
+      * `value`: the whole hot path (assembly, Cholesky, two solve pairs) of a small instance of the same generator;
+      * `scaled_instance`: SURVEY.md section 8d's scaled instance (matrix side 500, 1000 constraints): the
+        constraint loop of makeBBBBsi (src/makeBBBB.jl:77) is timed for its first `sample2` constraints -- every
+        pass does the same work: two msz^3 products and one AA * vec(tmp) over all nvar rows -- and scaled by
+        nvar / sample2; factor + solves are timed on the GPU-assembled matrix of the full instance."""
+    import numpy as np
+    import scipy.linalg as sla
+    from oracle import loraine_oracle as lo
+    rows, AA, sigmaA, qA, rng = _dense_instance(msz, nvar, seed)
+    W, G = make_scaling(msz, seed + 1)
+    h1, h2 = rng.standard_normal(nvar), rng.standard_normal(nvar)
+    t0 = time.perf_counter()
+    H = lo.makeBBBBsi(0, _DenseRows(rows, msz), AA, W, nvar, qA, sigmaA)
+    Hl = np.tril(H)
+    L = np.linalg.cholesky(Hl + np.tril(Hl, -1).T)
+    for h in (h1, h2):
+        x = sla.solve_triangular(L.T, sla.solve_triangular(L, h, lower=True), lower=False)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    gpu_ms, xg = _gpu_same_sample(rows, AA, sigmaA, qA, msz, W, G, h1, h2)
+    err = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
     fl = flops_model(msz, nvar)
-    return {
+    out = {
         "value": cpu_ms, "unit": "ms/IP-iteration (Schur assembly + solve) on the sample instance",
         "cores": os.cpu_count(), "kind": "port",
         "sample": f"same generator, dense SDP matrix side {msz}, {nvar} constraints "
                   f"({fl / 1e9:.1f} GFLOP algorithmic); CPU = NumPy/SciPy restatement of the reference path "
-                  f"(OpenBLAS GEMM threads = all host cores, SciPy SpMV single-threaded)",
+                  f"(OpenBLAS GEMM threads = all host cores, SciPy SpMV single-threaded like SparseArrays')",
         "cpu_gflops": fl / cpu_ms / 1e6,
         "gpu_ms_same_sample": gpu_ms,
         "gpu_vs_cpu_rel_err_dely": err,
     }
+    if msz2 > 0 and nvar2 > 0 and sample2 > 0:
+        del rows, AA, H, Hl, L
+        rows, AA, sigmaA, qA, rng = _dense_instance(msz2, nvar2, seed + 11)
+        W, G = make_scaling(msz2, seed + 12)
+        h1, h2 = rng.standard_normal(nvar2), rng.standard_normal(nvar2)
+        q = min(sample2, nvar2)
+        t0 = time.perf_counter()
+        Hs = lo.makeBBBBsi(0, _DenseRows(rows, msz2), AA, W, nvar2, qA, sigmaA, ii_stop=q)
+        loop_ms = (time.perf_counter() - t0) * 1e3
+        gpu2_ms, xg2 = _gpu_same_sample(rows, AA, sigmaA, qA, msz2, W, G, h1, h2)
+        # factor + solves on the full Schur matrix: rebuild it from the solution-independent identity H = AA T' ...
+        # cheaper: time them on the GPU-assembled H of the same instance
+        import loraine_jl_amd
+        dev = loraine_jl_amd.Device(0)
+        dev.set_option("dense_threshold", 1)
+        dev.upload_model([AA], sigmaA, qA, [msz2])
+        dev.set_scaling(0, W, G)
+        Hfull = dev.schur_assemble(0, want_H=True)
+        dev.close()
+        # the sampled columns against the full GPU matrix: the CPU sample computed columns sigma[0:q] completely
+        cols = sigmaA[:q, 0]
+        col_err = float(np.linalg.norm(Hs[:, cols] - Hfull[:, cols]) / np.linalg.norm(Hfull[:, cols]))
+        t0 = time.perf_counter()
+        L = np.linalg.cholesky(Hfull)
+        for h in (h1, h2):
+            x = sla.solve_triangular(L.T, sla.solve_triangular(L, h, lower=True), lower=False)
+        fs_ms = (time.perf_counter() - t0) * 1e3
+        fl2 = flops_model(msz2, nvar2)
+        scaled = loop_ms * nvar2 / q + fs_ms
+        out["scaled_instance"] = {
+            "msz": msz2, "nvar": nvar2, "sampled_constraints": q, "constraint_loop_ms_sampled": loop_ms,
+            "factor_and_solves_ms": fs_ms, "value_scaled_ms": scaled,
+            "scaling": f"constraint-loop time of the first {q} of {nvar2} constraints x {nvar2}/{q} + factor and "
+                       f"two solve pairs of the full {nvar2} x {nvar2} Schur matrix (timed in full)",
+            "cpu_gflops": fl2 / scaled / 1e6, "gpu_ms_same_instance": gpu2_ms,
+            "sampled_columns_rel_err_vs_gpu": col_err,
+            "gpu_vs_cpu_rel_err_dely": float(np.linalg.norm(xg2 - x) / np.linalg.norm(x)),
+        }
+    return out
 
 
 def self_launch(args):
@@ -374,7 +451,8 @@ def main():
             out["exchange_ms_per_step"] = t_exchange[0] / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             dev.close()
-            out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7, args.cpu_msz2,
+                                               args.cpu_nvar2, args.cpu_sample2)
         print(json.dumps(out), flush=True)
     if sharded:
         dist.barrier()

@@ -189,7 +189,12 @@ int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top
 /* ---- measurement ----------------------------------------------------------------------- */
 /* milliseconds of the named phase in the last call that ran it, measured with HIP events
  * on the context's stream ("gemm1","gemm2","gemm3","sparse","assemble","factor","solve",...);
- * returns LRN_ERR_ARG for an unknown key. */
+ * returns LRN_ERR_ARG for an unknown key.  The reference's TimerOutputs section names are accepted as aliases:
+ * "BBBBone1" (mul!(tmp1,W,A_i), src/makeBBBB.jl:87) = gemm1, "BBBBone2" (tmp1*W, :90) = gemm2, "BBBBone3"
+ * (AA*vec(tmp), :94) = gemm3 + reduce3, "BBBBone4" (:98, the scatter into BBBB) = 0: it is the GEMM3 epilogue,
+ * "BBBBone" (:86), "BBBBthree" (:140) = sparse, "BBBB_rank1" (:2) = rank1, "BBBBs" (:30) = assemble, "Ax"
+ * (src/Solvers.jl:583) = matvec, "prec" (:676) = prec_setup, "prep W SVD" (src/prepare_W.jl:37) = prepw_svd,
+ * "CG predictor" / "CG corrector" (src/predictor_corrector.jl:130,234) = pcg, "find step corrector" (:243). */
 int lrn_get_timing(lrn_ctx* ctx, const char* key, double* ms);
 /* launch / event counters of the same phases; "shard_bs" returns the column-block width of the Schur
  * sharding in effect (option "shard_bs": 0 = auto, two 128-aligned blocks per rank) */

@@ -415,31 +415,37 @@ def makeBBBBsi_literal(ilmi, Ailmi, AAilmi, Wilmi, n, qA, sigmaA):
     return BBBB
 
 
-def makeBBBBsi(ilmi, Ailmi, AAilmi, Wilmi, n, qA, sigmaA):
+def makeBBBBsi(ilmi, Ailmi, AAilmi, Wilmi, n, qA, sigmaA, ii_stop=None):
     """src/makeBBBB.jl:67-218 -- same branch structure and write pattern as the reference,
-    with the inner j-loops vectorised (row i against all j at once)."""
+    with the inner j-loops vectorised (row i against all j at once).  `ii_stop` (bench.py's bounded CPU sample
+    only): leave the constraint loop :77 after that many positions."""
     m = Wilmi.shape[0]
     BBBB = np.zeros((n, n))
-    AAc = AAilmi.tocsr()
-    nnz_per = np.diff(AAc.indptr)
-    # union pattern P of vec-positions touched by any constraint
-    P = np.unique(AAc.indices)
-    Pp = P % m
-    Pq = P // m
-    AAP = AAc[:, P].tocsr()         # n x |P|
-    rank = np.empty(n, dtype=np.int64)
-    rank[sigmaA[:, ilmi]] = np.arange(n)
-    for ii in range(n):
+    nnz_per = np.asarray(AAilmi.getnnz(axis=1)).ravel()
+    pat = {}
+
+    def pattern():
+        # union pattern P of vec-positions touched by any constraint (sparse branches only: built on first use)
+        if not pat:
+            AAc = AAilmi.tocsr()
+            P = np.unique(AAc.indices)
+            pat.update(P=P, Pp=P % m, Pq=P // m, AAP=AAc[:, P].tocsr())         # AAP: n x |P|
+        return pat["P"], pat["Pp"], pat["Pq"], pat["AAP"]
+
+    nnz_all = int(nnz_per.sum())
+    for ii in range(n if ii_stop is None else min(n, ii_stop)):
         i = sigmaA[ii, ilmi]
         if nnz_per[i] == 0:
             continue
         Ai = Ailmi[i + 1].tocoo()
         if ii < qA[0, ilmi]:
-            if Ai.nnz * 4 > m * m or P.size * 8 > m * m:
+            # (the union pattern is at least nnz_all / n wide: dense data never builds it)
+            if Ai.nnz * 4 > m * m or nnz_all * 8 > n * m * m or pattern()[0].size * 8 > m * m:
                 tmp = (Wilmi @ Ailmi[i + 1].toarray()) @ Wilmi
                 tmp2 = AAilmi @ vec(tmp)
             else:
                 # T_i on the union pattern only: T[p,q] = sum_(r,c) a_rc W[p,r] W[c,q]
+                P, Pp, Pq, AAP = pattern()
                 tP = np.zeros(P.size)
                 for r, c, a in zip(Ai.row, Ai.col, Ai.data):
                     tP += a * Wilmi[Pp, r] * Wilmi[c, Pq]
@@ -448,6 +454,7 @@ def makeBBBBsi(ilmi, Ailmi, AAilmi, Wilmi, n, qA, sigmaA):
             BBBB[indi, i] = -tmp2[indi]
             BBBB[i, indi] = -tmp2[indi]
         else:
+            P, Pp, Pq, AAP = pattern()
             tP = np.zeros(P.size)
             for r, c, a in zip(Ai.row, Ai.col, Ai.data):
                 tP += a * Wilmi[Pp, r] * Wilmi[c, Pq]
