@@ -16,6 +16,7 @@ const LIB = get(ENV, "LORAINE_HIP_LIB", joinpath(@__DIR__, "..", "loraine.jl_amd
 
 mutable struct Ctx
     h::Ptr{Cvoid}
+    chol_is_object::Bool      # this IP iteration's factor came out of the +1e-4*I loop (predictor_corrector.jl:85)
 end
 
 function check(ctx::Ctx, rc::Cint, what)
@@ -28,7 +29,7 @@ function Ctx(device::Integer = 0)
     r = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:lrn_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), r, device)
     rc == 0 || error("lrn_create failed ($rc): no MI355X visible? (there is no CPU fallback)")
-    ctx = Ctx(r[])
+    ctx = Ctx(r[], false)
     finalizer(c -> ccall((:lrn_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), ctx)
     return ctx
 end
@@ -43,16 +44,22 @@ function upload_model!(ctx::Ctx, model)
     bcol = hasB ? [Vector{Int64}(model.B[i].colptr) for i in 1:nlmi] : Vector{Int64}[]
     brow = hasB ? [Vector{Int64}(model.B[i].rowval) for i in 1:nlmi] : Vector{Int64}[]
     bval = hasB ? [Vector{Float64}(model.B[i].nzval) for i in 1:nlmi] : Vector{Float64}[]
-    p(v) = isempty(v) ? C_NULL : pointer(map(pointer, v))
+    # The arrays of pointers are locals that `ccall` itself roots (passed as the Vector, converted to
+    # Ptr{Ptr{T}} by the call), and the arrays they point into are kept alive by GC.@preserve: nothing the
+    # library reads can be collected or moved during the call.  An empty list (no rank-one factors) is C_NULL.
+    cp_ptrs, rv_ptrs, nz_ptrs = map(pointer, colptr), map(pointer, rowval), map(pointer, nzval)
+    bc_ptrs, br_ptrs, bv_ptrs = map(pointer, bcol), map(pointer, brow), map(pointer, bval)
     cl = model.C_lin
-    GC.@preserve colptr rowval nzval bcol brow bval begin
+    msizes, sigmaA, qA = Vector{Int64}(model.msizes), Matrix{Int64}(model.sigmaA), Matrix{Int64}(model.qA)
+    lcp, lrv, lnz = Vector{Int64}(cl.colptr), Vector{Int64}(cl.rowval), Vector{Float64}(cl.nzval)
+    GC.@preserve colptr rowval nzval bcol brow bval cp_ptrs rv_ptrs nz_ptrs bc_ptrs br_ptrs bv_ptrs msizes sigmaA qA lcp lrv lnz begin
         rc = ccall((:lrn_upload_model, LIB), Cint,
             (Ptr{Cvoid}, Cint, Cint, Ptr{Int64}, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}},
              Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Int64}, Ptr{Int64},
              Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}),
-            ctx.h, nlmi, n, Vector{Int64}(model.msizes), p(colptr), p(rowval), p(nzval),
-            p(bcol), p(brow), p(bval), Matrix{Int64}(model.sigmaA), Matrix{Int64}(model.qA),
-            model.nlin, Vector{Int64}(cl.colptr), Vector{Int64}(cl.rowval), Vector{Float64}(cl.nzval))
+            ctx.h, nlmi, n, msizes, cp_ptrs, rv_ptrs, nz_ptrs,
+            hasB ? bc_ptrs : C_NULL, hasB ? br_ptrs : C_NULL, hasB ? bv_ptrs : C_NULL, sigmaA, qA,
+            model.nlin, lcp, lrv, lnz)
     end
     check(ctx, rc, "lrn_upload_model")
 end
@@ -100,6 +107,7 @@ end
 
 function factor!(ctx::Ctx, solver)          # predictor_corrector.jl:55-85
     info = Ref{Cint}(0)
+    ctx.chol_is_object = false
     check(ctx, ccall((:lrn_schur_factor, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), ctx.h, info), "lrn_schur_factor")
     info[] == 0 && return true
     solver.regcount += 1
@@ -107,15 +115,22 @@ function factor!(ctx::Ctx, solver)          # predictor_corrector.jl:55-85
     for _ in 1:1001
         check(ctx, ccall((:lrn_schur_add_diag, LIB), Cint, (Ptr{Cvoid}, Cdouble), ctx.h, 1e-4), "lrn_schur_add_diag")
         check(ctx, ccall((:lrn_schur_factor, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), ctx.h, info), "lrn_schur_factor")
-        info[] == 0 && return true
+        # :85 stores the Cholesky OBJECT here (the factor L otherwise, :57-58): `cholBBBB' \ (cholBBBB \ h)` then
+        # solves twice until the next factorisation -- kept, so the iterates stay the reference's
+        info[] == 0 && (ctx.chol_is_object = true; return true)
     end
     solver.status = 3
     return false
 end
 
-function solve(ctx::Ctx, h::Vector{Float64})   # L' \ (L \ h)
+function solve(ctx::Ctx, h::Vector{Float64})   # cholBBBB' \ (cholBBBB \ h)  (predictor_corrector.jl:90,199)
     x = similar(h)
     check(ctx, ccall((:lrn_schur_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, h, x), "lrn_schur_solve")
+    if ctx.chol_is_object                       # regularised iteration: H_reg^-1 (H_reg^-1 h), as the reference
+        y = similar(h)
+        check(ctx, ccall((:lrn_schur_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, x, y), "lrn_schur_solve")
+        return y
+    end
     return x
 end
 

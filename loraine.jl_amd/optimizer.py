@@ -29,10 +29,13 @@ class UnsupportedAttribute(KeyError):
 
 
 class Optimizer:
-    def __init__(self, device=None, device_index=0, resident=True):
+    def __init__(self, device=None, device_index=0, resident=True, exact_regularised_solve=False):
         # resident=True: X, S and all msz x msz work stay on the device (resident.ResidentSolver);
         # resident=False: step-length search / convergence test in host NumPy (solvers.MySolver)
         self.resident = resident
+        # False (default): regularised iterations solve twice, like the reference (src/predictor_corrector.jl:85,90);
+        # True: (H + d I)^-1 h.  Not one of the reference's 15 options -- a constructor argument.
+        self.exact_regularised_solve = bool(exact_regularised_solve)
         self.solver = None
         self.halpha = None
         self.max_sense = False
@@ -95,6 +98,7 @@ class Optimizer:
             self.solver, self.halpha = resident.load(model, opts, device=self._device)
         else:
             self.solver, self.halpha = solvers.load(model, opts, device=self._device)
+        self.solver.exact_regularised_solve = self.exact_regularised_solve
 
     def optimize(self):                        # MOI.optimize! (:136-140)
         if self._pending is None:

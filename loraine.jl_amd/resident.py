@@ -94,7 +94,7 @@ class ResidentSolver(MySolver):
         if self.kit == 0:
             if not self._factor_with_regularisation():
                 return
-            self.dely = dev.schur_solve(h)                                   # [GPU]
+            self.dely = self._schur_solve(h)                                 # [GPU]
         else:
             self.dely, it = self._cg(h, True, halpha)
             self.cg_iter_pre += it
@@ -127,7 +127,7 @@ class ResidentSolver(MySolver):
             t = (self.delX_lin * self.delS_lin) * self.Si_lin - (self.sigma * self.mu) * self.Si_lin
             h += m.C_lin @ ((self.X_lin * self.Si_lin) * self.Rd_lin + self.X_lin + t)
         if self.kit == 0:
-            self.dely = self.dev.schur_solve(h)
+            self.dely = self._schur_solve(h)
         else:
             self.dely, it = self._cg(h, False, halpha)
             self.cg_iter_cor += it

@@ -125,6 +125,8 @@ class MySolver:
         self.alpha = np.zeros(m.nlmi)
         self.beta = np.zeros(m.nlmi)
         self.regcount = 0
+        self.chol_is_object = False
+        self.exact_regularised_solve = False   # True: (H + d I)^-1 h instead of the reference's double solve
         if self.kit == 1:
             if m.nlmi == 0:
                 self._say("WARNING: Switching to a direct solver, no LMIs")
@@ -196,6 +198,7 @@ class MySolver:
 
     def _factor_with_regularisation(self):
         """cholesky(BBBB) + the 1e-4*I loop of src/predictor_corrector.jl:55-85 [GPU]."""
+        self.chol_is_object = False
         info = self.dev.schur_factor()
         if info == 0:
             return True
@@ -208,9 +211,21 @@ class MySolver:
             self.dev.schur_add_diag(1e-4)
             if self.dev.schur_factor() == 0:
                 self.reg_adds = k + 1
+                # the reference stores the Cholesky OBJECT in this branch (:85) and the factor L otherwise (:57-58), so
+                # its `cholBBBB' \ (cholBBBB \ h)` (:90, :199) solves twice for the rest of this IP iteration
+                self.chol_is_object = not self.exact_regularised_solve
                 return True
         self.status = 3
         return False
+
+    def _schur_solve(self, h):
+        """`cholBBBB' \ (cholBBBB \ h)` (src/predictor_corrector.jl:90,199) [GPU]; in a regularised iteration the
+        reference's operand is a Cholesky object and the expression is H_reg^-1 (H_reg^-1 h) -- reproduced unless the
+        solver was created with exact_regularised_solve=True (divergences)."""
+        x = self.dev.schur_solve(h)
+        if self.chol_is_object:
+            x = self.dev.schur_solve(x)
+        return x
 
     def _cg(self, h, setup, halpha):
         if setup:
@@ -258,7 +273,7 @@ class MySolver:
         if self.kit == 0:
             if not self._factor_with_regularisation():
                 return
-            self.dely = dev.schur_solve(h)                                     # [GPU] L'\(L\h)
+            self.dely = self._schur_solve(h)                                   # [GPU] L'\(L\h)
         else:
             self.dely, it = self._cg(h, True, halpha)
             self.cg_iter_pre += it
@@ -294,7 +309,7 @@ class MySolver:
             t = (self.delX_lin * self.delS_lin) * self.Si_lin - (self.sigma * self.mu) * self.Si_lin
             h += m.C_lin @ ((self.X_lin * self.Si_lin) * self.Rd_lin + self.X_lin + t)
         if self.kit == 0:
-            self.dely = self.dev.schur_solve(h)                                # [GPU] :199
+            self.dely = self._schur_solve(h)                                   # [GPU] :199
         else:
             self.dely, it = self._cg(h, False, halpha)
             self.cg_iter_cor += it
@@ -463,7 +478,7 @@ class MySolver:
                 schur_chol=d.count("schur_chol"), schur_via_l=d.count("schur_via_l"), wchol_fail=d.count("wchol_fail"),
                 alpha=[float(a) for a in self.alpha] + [float(self.alpha_lin)],
                 beta=[float(b) for b in self.beta] + [float(self.beta_lin)], regcount=self.regcount,
-                reg_adds=getattr(self, "reg_adds", 0)))
+                reg_adds=getattr(self, "reg_adds", 0), chol_boosted=d.count("chol_boosted")))
             if time.perf_counter() - t1 > getattr(self, "time_budget", float("inf")):
                 self.status = 4            # tools/c5_solve.py: wall-clock cap for exploratory runs
             if self.preconditioner == 4:

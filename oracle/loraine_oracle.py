@@ -869,6 +869,7 @@ def predictor(solver, halpha):
         t0 = time.perf_counter()
         Hl = np.tril(BBBB)                       # Hermitian(BBBB,:L)  :39
         Hs = Hl + np.tril(Hl, -1).T
+        solver.chol_is_object = False
         try:
             L = np.linalg.cholesky(Hs)           # :57
         except np.linalg.LinAlgError:
@@ -881,6 +882,7 @@ def predictor(solver, halpha):
             while True:
                 try:
                     L = np.linalg.cholesky(Hs)
+                    solver.reg_adds = icount
                     break
                 except np.linalg.LinAlgError:
                     Hs = Hs + 1e-4 * np.eye(m.n)
@@ -889,8 +891,13 @@ def predictor(solver, halpha):
                         solver.cholBBBB = np.eye(m.n)
                         solver.status = 3
                         return
+            # :85 stores the Cholesky OBJECT here, where :57-58 keeps the factor L: `cholBBBB' \ (cholBBBB \ h)`
+            # (:90, :199) is then H_reg^-1 (H_reg^-1 h) for the rest of this IP iteration -- restated as is
+            solver.chol_is_object = True
         solver.cholBBBB = L
         solver.dely = sla.solve_triangular(L.T, sla.solve_triangular(L, h, lower=True), lower=False)  # :90
+        if solver.chol_is_object:
+            solver.dely = sla.solve_triangular(L.T, sla.solve_triangular(L, solver.dely, lower=True), lower=False)
         solver.t_solve = time.perf_counter() - t0
     else:
         t0 = time.perf_counter()
@@ -952,6 +959,8 @@ def corrector(solver, halpha):
     if solver.kit == 0:
         L = solver.cholBBBB
         solver.dely = sla.solve_triangular(L.T, sla.solve_triangular(L, h, lower=True), lower=False)  # :199
+        if getattr(solver, "chol_is_object", False):
+            solver.dely = sla.solve_triangular(L.T, sla.solve_triangular(L, solver.dely, lower=True), lower=False)
     else:
         A = MyA(solver.W, m.AA, m.nlin, m.C_lin, solver.X_lin, solver.S_lin_inv)
         if solver.preconditioner == 0:
@@ -1126,6 +1135,7 @@ def solve(solver, halpha=None):
             dimacs=solver.DIMACS_error,
             errs=(solver.err1, solver.err2, solver.err3, solver.err4, solver.err5, solver.err6),
             mu=solver.mu, sigma=solver.sigma, cg_pre=solver.cg_iter_pre, cg_cor=solver.cg_iter_cor,
+            regcount=solver.regcount, reg_adds=getattr(solver, "reg_adds", 0),
             t_prepw=getattr(solver, "t_prepw", 0.0), t_assembly=getattr(solver, "t_assembly", 0.0),
             t_solve=getattr(solver, "t_solve", 0.0), itertime=solver.itertime))
         if solver.preconditioner == 4:
