@@ -61,12 +61,14 @@ struct LrnOptions {
   double dense_threshold = -1.0;  // < 0: cost model decides which constraints are stored dense
   long t_batch = 0, p_batch = 0;  // matrices per T workspace / per GEMM1-2 launch (0 = auto)
   int prec_eig = 0;               // 0 auto (Lanczos for msz >= 256), 1 Jacobi eigendecomposition, 2 Lanczos
-  double pivot_boost = 0.0;       // lrn_schur_factor: 0 = strict LAPACK behaviour (the reference's), > 0 boosts
-                                  // pivots <= pivot_boost * diag (opt-in)
+  double pivot_boost = 1e-12;     // lrn_schur_factor: pivots <= pivot_boost * diag (rounding noise of a matrix that is
+                                  // PSD by construction) are boosted instead of failing, counted in "chol_boosted";
+                                  // 0 = strict Cholesky, the literal LAPACK behaviour
   int schur_chol = -1;            // -1 auto, 0 never, 1 whenever the data allows it, 2 T-via-L only
   int schur_plan = -1;            // multi-GPU: the exchange all ranks agreed on (-1 undecided, 0 all-gather of
                                   // Schur column blocks, 1 all-reduce of partial sums); see lrn_schur_plan
   int gemm3_ksplit = 0;           // split-K factor of GEMM3 / GEMM3' (0 = auto)
+  int gemm_no_skip = 0;           // measurement only: GEMM1'/2'/3' compute every 16x16 block (GEMM_NO_SKIP)
   int gemm3_stagger = 0;          // K-walk stagger of GEMM3' in chunks of 16 (GemmDesc::kstagger)
   int svd_sdc = 0, sdc_min = 4000, sdc_leaf = 768;
   double sdc_l0 = 1e-6;

@@ -19,6 +19,7 @@
 //    (deterministic; no float atomics).
 #include "lrn_common.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -39,6 +40,14 @@ struct GemmParams {
 };
 
 #define MFMA_F64_ROW(lane, r) (((lane) >> 4) + 4 * (r))
+// An MFMA that accumulates IN PLACE behind a wave-uniform `if (block is needed)`.  One masked body serves every K-step
+// (a second, unconditional copy of the body for the common all-blocks case made the compiler hoist the fragment loads
+// of both copies above the branch: 256 VGPRs and > 100 spilled); the tied "+v" operand keeps each accumulator in its
+// registers across the 16 branches of a K-quarter.  Inline asm is invisible to the hazard recogniser: the operands come
+// from ds_read (ordered by s_waitcnt, which does see asm operands), a dependent MFMA on the same accumulator needs
+// no wait states, and the one VALU read of the accumulators -- the epilogue -- is behind LRN_MFMA_DRAIN.
+#define LRN_MFMA_INPLACE(c, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+#define LRN_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 
 template <int BM, bool KC>
 __device__ __forceinline__ int lds_idx(int m, int k) {
@@ -64,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
     tm = tt.x;
     tn = tt.y;
   }
+  if (tm < 0) return;      // padding entry of the tile list
   const int ks = blockIdx.z % d.ksplit;
   const int bz = blockIdx.z / d.ksplit;
   const double* __restrict__ Ag = d.A + (long)bz * d.bA;
@@ -268,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     tm = tt.x;
     tn = tt.y;
   }
+  if (tm < 0) return;      // padding entry of the tile list
   const int bz = blockIdx.z;
   const double* Ag = d.A + (long)bz * d.bA;
   const double* Bg = d.B + (long)bz * d.bB;
@@ -316,11 +327,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   };
 
   const int fr = lane & 15, fk = lane >> 4;
+  // ---- which 16x16 blocks this wave computes.  Wave (wm, wn) owns the blocks (bm, bn) = (2 i + wm, 2 j + wn),
+  // i, j < 4, of the 8 x 8 blocks of the tile -- INTERLEAVED, so that whatever part of a tile need not be computed
+  // (blocks beyond M / N at the edges, the blocks above the diagonal of a packed diagonal tile, and, K-step by
+  // K-step, the blocks a triangular operand leaves zero) is shared evenly by the four waves: a tile costs its
+  // busiest wave.  Bit i * 4 + j of a mask = block (i, j) of this wave; masks are wave-uniform (SGPR).
+  unsigned smask = 0;
+  {
+    const bool diag_pk = EPI && (d.flags & GEMM_C_PACKED) && tm == tn;   // stored: blocks with bn >= bm only
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int bm = 2 * i + wm, bn = 2 * j + wn;
+        bool need = (m0 + 16 * bm < d.M) && (n0 + 16 * bn < d.N);
+        if (diag_pk && bn < bm) need = false;
+        if (d.flags & GEMM_NO_SKIP) need = true;
+        if (need) smask |= 1u << (i * 4 + j);
+      }
+  }
+  const bool from_n = d.flags & GEMM_KFROM_N, from_m = d.flags & GEMM_KFROM_M;
+  const bool to_n = d.flags & GEMM_KTO_N, to_m = d.flags & GEMM_KTO_M;
   // K loop from the tile origin when an operand is triangular (tile origins are multiples of 128)
-  const int kt0 = (d.flags & GEMM_KFROM_N) ? n0 / BK : ((d.flags & GEMM_KFROM_M) ? m0 / BK : 0);
-  issue(kt0, kt0 & 1);
-  __syncthreads();
-  for (int kt = kt0; kt < nk; ++kt) {
+  const int kt0 = from_n ? n0 / BK : (from_m ? m0 / BK : 0);
+  // Three loops over K with two bodies.  `fast`: all 16 blocks, the compiler's own schedule (builtin MFMAs, fragment
+  // reads of the next quarter hoisted over the current one).  `masked`: a wave-uniform branch per block -- only for
+  // the K-steps that cross the tile's own diagonal block of a triangular operand (the first 8 of KFROM, the last 8 of
+  // KTO), and for every K-step of a tile with blocks to skip (edges, packed diagonal tiles).  Kept as SEPARATE loops:
+  // as two branches of one loop body the compiler merges their identical fragment loads above the branch and spills.
+  auto fast_step = [&](int kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
     const double* sa = lds + cur * (2 * LA);
@@ -329,9 +364,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     for (int kk = 0; kk < BK / 4; ++kk) {
       double fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = sa[(kk * 4 + fk) * LROW + wm * 64 + i * 16 + fr];
+      for (int i = 0; i < TM; ++i) fa[i] = sa[(kk * 4 + fk) * LROW + (2 * i + wm) * 16 + fr];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = sb[(kk * 4 + fk) * LROW + wn * 64 + j * 16 + fr];
+      for (int j = 0; j < TN; ++j) fb[j] = sb[(kk * 4 + fk) * LROW + (2 * j + wn) * 16 + fr];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -339,7 +374,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+  };
+  auto masked_step = [&](int kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+    const double* sa = lds + cur * (2 * LA);
+    const double* sb = sa + LA;
+    // blocks of this K-step: op(B)[k][n] = 0 for k < n (KFROM_N) means block column bn starts contributing at the
+    // K-step that reaches its first column, i.e. kt - n0/16 >= bn; KTO_N (zero for k > n): kt - n0/16 <= bn.
+    unsigned mask = smask;
+    const int sn = kt - n0 / BK, sm = kt - m0 / BK;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int bn = 2 * j + wn;
+      if ((from_n && sn < bn) || (to_n && sn > bn)) mask &= ~(0x1111u << j);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int bm = 2 * i + wm;
+      if ((from_m && sm < bm) || (to_m && sm > bm)) mask &= ~(0xfu << (4 * i));
+    }
+    if (mask != 0u) {
+      // all fragments of the K-step first (one exposed LDS latency instead of four: nothing is scheduled across the
+      // branches below), then the needed blocks
+      double fa[BK / 4][TM], fb[BK / 4][TN];
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[kk][i] = sa[(kk * 4 + fk) * LROW + (2 * i + wm) * 16 + fr];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[kk][j] = sb[(kk * 4 + fk) * LROW + (2 * j + wn) * 16 + fr];
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (mask & (1u << (i * 4 + j))) LRN_MFMA_INPLACE(acc[i][j], fa[kk][i], fb[kk][j]);
+    }
+    __syncthreads();
+  };
+  int head_end = kt0, tail_begin = nk;          // K-steps [kt0, head_end) and [tail_begin, nk) run masked
+  if (smask != 0xffffu) {
+    head_end = nk;
+  } else {
+    if (from_n | from_m) head_end = kt0 + 8 < nk ? kt0 + 8 : nk;
+    if (to_n) tail_begin = n0 / BK;
+    if (to_m && m0 / BK < tail_begin) tail_begin = m0 / BK;
+    if (d.flags & GEMM_NO_SKIP) { head_end = kt0; tail_begin = nk; }
+    if (tail_begin < head_end) tail_begin = head_end;
+    if (tail_begin > nk) tail_begin = nk;
   }
+  issue(kt0, kt0 & 1);
+  __syncthreads();
+  int kt = kt0;
+  for (; kt < head_end; ++kt) masked_step(kt);
+  for (; kt < tail_begin; ++kt) fast_step(kt);
+  for (; kt < nk; ++kt) masked_step(kt);
+  LRN_MFMA_DRAIN();
 
   const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
   const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
@@ -352,11 +445,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if (!(smask & (1u << (i * 4 + j)))) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int m = m0 + wm * 64 + i * 16 + MFMA_F64_ROW(lane, r);
-        int n = n0 + wn * 64 + j * 16 + fr;
+        int m = m0 + (2 * i + wm) * 16 + MFMA_F64_ROW(lane, r);
+        int n = n0 + (2 * j + wn) * 16 + fr;
         if (m < d.M && n < d.N) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
@@ -373,6 +467,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
           if (mir) Cg[(long)n * d.sCm + (long)m * d.sCn] = v;
         }
       }
+    }
 }
 
 // ------------------------------------------------------------------ direct-to-LDS, K-contiguous
@@ -400,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
     tm = tt.x;
     tn = tt.y;
   }
+  if (tm < 0) return;      // padding entry of the tile list
   const int ks = blockIdx.z % d.ksplit;
   const int bz = blockIdx.z / d.ksplit;
   const double* Ag = d.A + (long)bz * d.bA;
@@ -443,6 +539,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
+  // a diagonal tile of a symmetric rank-k update (same operand, same rows): ONE panel serves as both images -- half
+  // the loads of the tiles that, computing 10 of their 16 blocks, would otherwise be bound by the panel traffic
+  const bool same_panel = (Ag == Bg) && (m0 == n0) && (d.sAm == d.sBn) && (d.M == d.N);
   auto issue = [&](long kb, int buf) {
     double* sa = lds + buf * (2 * LA);
     double* sb = sa + LA;
@@ -451,8 +550,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
       const int r8 = 8 * (w + 4 * j);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kb),
                                        (__attribute__((address_space(3))) void*)(sa + r8 * BK), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j] + kb),
-                                       (__attribute__((address_space(3))) void*)(sb + r8 * BK), 16, 0, 0);
+      if (!same_panel)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j] + kb),
+                                         (__attribute__((address_space(3))) void*)(sb + r8 * BK), 16, 0, 0);
     }
   };
   auto next_chunk = [&]() {
@@ -466,6 +566,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   };
 
   const int fr = lane & 15, fk = lane >> 4;
+  // blocks of this wave: (bm, bn) = (2 i + wm, 2 j + wn), interleaved like in gemm_f64_lds_kernel, so that the
+  // blocks beyond M / N (nvar = 4000: the last tile row holds 32 of 128 rows) and, with GEMM_DIAG_LOWER, the blocks
+  // above the diagonal of a diagonal tile are skipped evenly by the four waves
+  unsigned smask = 0;
+  {
+    const bool diag_lo = (d.flags & GEMM_DIAG_LOWER) && tm == tn;
+    const bool diag_up = (d.flags & GEMM_DIAG_UPPER) && tm == tn;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int bm = 2 * i + wm, bn = 2 * j + wn;
+        bool need = (m0 + 16 * bm < d.M) && (n0 + 16 * bn < d.N);
+        if ((diag_lo && bm < bn) || (diag_up && bn < bm)) need = false;
+        if (d.flags & GEMM_NO_SKIP) need = true;
+        if (need) smask |= 1u << (i * 4 + j);
+      }
+  }
   bool more = FLAT ? left > 0 : segc < segcend;
   if (more) {
     issue(chunk_base(), 0);
@@ -473,48 +591,92 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   }
   __syncthreads();
   int cur = 0;
-  while (more) {
-    const bool have_next = FLAT ? left > 0 : segc < segcend;
-    if (have_next) {
-      issue(chunk_base(), cur ^ 1);
-      next_chunk();
-    }
-    const double* sa = lds + cur * (2 * LA);
-    const double* sb = sa + LA;
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double fa[TM], fb[TN];
-      const int k = kk * 4 + fk;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int row = wm * 64 + i * 16 + fr;
-        fa[i] = sa[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+  // two copies of the K loop (see gemm_f64_lds_kernel): the unmasked one for tiles whose 16 blocks are all needed,
+  // the masked one for edge and diagonal tiles
+  if (smask == 0xffffu) {
+    while (more) {
+      const bool have_next = FLAT ? left > 0 : segc < segcend;
+      if (have_next) {
+        issue(chunk_base(), cur ^ 1);
+        next_chunk();
       }
+      const double* sa = lds + cur * (2 * LA);
+      const double* sb = same_panel ? sa : sa + LA;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        int row = wn * 64 + j * 16 + fr;
-        fb[j] = sb[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double fa[TM], fb[TN];
+        const int k = kk * 4 + fk;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          int row = (2 * i + wm) * 16 + fr;
+          fa[i] = sa[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          int row = (2 * j + wn) * 16 + fr;
+          fb[j] = sb[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      __syncthreads();
+      cur ^= 1;
+      more = have_next;
     }
-    __syncthreads();
-    cur ^= 1;
-    more = have_next;
+  } else {
+    while (more) {
+      const bool have_next = FLAT ? left > 0 : segc < segcend;
+      if (have_next) {
+        issue(chunk_base(), cur ^ 1);
+        next_chunk();
+      }
+      const double* sa = lds + cur * (2 * LA);
+      const double* sb = same_panel ? sa : sa + LA;
+      if (smask != 0u) {
+        double fa[BK / 4][TM], fb[BK / 4][TN];      // all fragments of the K-step first (see gemm_f64_lds_kernel)
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+          const int k = kk * 4 + fk;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            int row = (2 * i + wm) * 16 + fr;
+            fa[kk][i] = sa[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            int row = (2 * j + wn) * 16 + fr;
+            fb[kk][j] = sb[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              if (smask & (1u << (i * 4 + j))) LRN_MFMA_INPLACE(acc[i][j], fa[kk][i], fb[kk][j]);
+      }
+      __syncthreads();
+      cur ^= 1;
+      more = have_next;
+    }
   }
+  LRN_MFMA_DRAIN();
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      if (!(smask & (1u << (i * 4 + j)))) continue;       // (GEMM_DIAG_LOWER: those slab entries are never read)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int m = m0 + wm * 64 + i * 16 + MFMA_F64_ROW(lane, r);
-        int n = n0 + wn * 64 + j * 16 + fr;
+        int m = m0 + (2 * i + wm) * 16 + MFMA_F64_ROW(lane, r);
+        int n = n0 + (2 * j + wn) * 16 + fr;
         if (m < d.M && n < d.N) Cg[(long)m * d.sCm + (long)n * d.sCn] = d.alpha * acc[i][j][r];
       }
+    }
 }
 
 static bool kseg_lds_path_ok(const GemmDesc& d) {
@@ -541,8 +703,18 @@ static bool lds_path_ok(const GemmDesc& d) {
 // (tm, tn) enumeration: 8x8 super-tiles (tm fastest inside), only the tiles a TRI flag keeps.
 // Consecutive list entries share operand panels, and the XCD swizzle hands each XCD a
 // contiguous run of the list, so co-resident workgroups of one L2 re-use panels.
-static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count) {
-  struct Key { int a, b, c; bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); } };
+// `short_sel`: 0 all tiles; 1 only the tiles whose 16 blocks are all computed ("regular"); 2 only the others -- the
+// tiles of the last tile row / column when `edge_m` / `edge_n` (M, N not multiples of the tile) and the diagonal
+// tiles when `diag` (GEMM_DIAG_*).  The K-contiguous rank-k update runs them as two launches: its workgroups are all
+// equally long and advance in lock-step through K (that is where its L2 hits come from); shorter workgroups mixed in
+// break the step -- measured at C4: 496 -> 520 ms although 7 % of the MFMAs were skipped.
+static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count, int short_sel = 0, bool edge_m = false,
+                                 bool edge_n = false, bool diag = false) {
+  struct Key {
+    int a, b, c;
+    bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); }
+  };
+  tri |= short_sel << 8 | (edge_m ? 1 << 12 : 0) | (edge_n ? 1 << 13 : 0) | (diag ? 1 << 14 : 0);
   struct Val { int2* dev; int n; };
   static std::map<Key, Val> cache[16];
   static std::mutex mu;                       // contexts on several host threads share the cache
@@ -559,10 +731,27 @@ static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count) {
     for (int sm = 0; sm < tilesM; sm += GS)
       for (int tn = sn; tn < sn + GS && tn < tilesN; ++tn)
         for (int tm = sm; tm < sm + GS && tm < tilesM; ++tm) {
-          if (tri == GEMM_TRI_LOWER && tn > tm) continue;
-          if (tri == GEMM_TRI_UPPER && tm > tn) continue;
+          if ((tri & 3) == GEMM_TRI_LOWER && tn > tm) continue;
+          if ((tri & 3) == GEMM_TRI_UPPER && tm > tn) continue;
+          const bool shrt = (edge_m && tm == tilesM - 1) || (edge_n && tn == tilesN - 1) || (diag && tm == tn);
+          if ((short_sel == 1 && shrt) || (short_sel == 2 && !shrt)) continue;
           v.push_back(make_int2(tm, tn));
         }
+  if (short_sel == 2 && diag) {
+    // every XCD walks one contiguous run of the list: deal the diagonal tiles (10 of 16 blocks per wave) and the
+    // edge tiles (a quarter of the rows) alternately, so that the runs are equally long
+    std::vector<int2> dg, ed, mix;
+    for (auto& t : v) (t.x == t.y ? dg : ed).push_back(t);
+    for (size_t i = 0; i < std::max(dg.size(), ed.size()); ++i) {
+      if (i < dg.size()) mix.push_back(dg[i]);
+      if (i < ed.size()) mix.push_back(ed[i]);
+    }
+    v.swap(mix);
+  }
+  // The kernels take blockIdx.x % 8 for the XCD of a workgroup (flat id % 8 in hardware): true for every z-slice of
+  // the grid only if the list length is a multiple of 8 -- pad with entries whose workgroups exit at once.
+  const int n_real = (int)v.size();
+  while (n_real > 0 && (v.size() & 7)) v.push_back(make_int2(-1, -1));
   Val val{nullptr, (int)v.size()};
   if (hipMalloc(&val.dev, sizeof(int2) * (v.size() + 1)) != hipSuccess) { *count = 0; return nullptr; }
   (void)hipMemcpy(val.dev, v.data(), sizeof(int2) * v.size(), hipMemcpyHostToDevice);
@@ -609,6 +798,8 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     std::swap(d.M, d.N);
     if (d.flags & GEMM_TRI_LOWER) d.flags = (d.flags & ~GEMM_TRI_LOWER) | GEMM_TRI_UPPER;
     else if (d.flags & GEMM_TRI_UPPER) d.flags = (d.flags & ~GEMM_TRI_UPPER) | GEMM_TRI_LOWER;
+    if (d.flags & GEMM_DIAG_LOWER) d.flags = (d.flags & ~GEMM_DIAG_LOWER) | GEMM_DIAG_UPPER;
+    else if (d.flags & GEMM_DIAG_UPPER) d.flags = (d.flags & ~GEMM_DIAG_UPPER) | GEMM_DIAG_LOWER;
   }
   const bool tri = d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER);
   const bool kflat = d.flags & GEMM_KFLAT;
@@ -675,7 +866,11 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     p.kchunk = (int)per;
   }
   int ntile = 0;
-  p.tile_list = get_tile_list(p.tilesM, p.tilesN, d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER), &ntile);
+  if (d.tile_class != 0 && small) return gemm_fail(LRN_ERR_ARG, "gemm: tile_class needs the 128 tile");
+  p.tile_list = get_tile_list(p.tilesM, p.tilesN, d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER), &ntile, d.tile_class,
+                              d.tile_class != 0 && (d.M % BMv) != 0, d.tile_class != 0 && (d.N % BMv) != 0,
+                              d.tile_class != 0 && (d.flags & (GEMM_DIAG_LOWER | GEMM_DIAG_UPPER)) != 0);
+  if (d.tile_class != 0 && p.tile_list && ntile == 0) return LRN_OK;      // nothing of that class
   if (!p.tile_list || ntile <= 0) return gemm_fail(LRN_ERR_NOMEM, "gemm: tile list allocation failed");
   (void)tri;
   const bool akc = (d.sAk == 1 && d.sAm != 1);

@@ -57,6 +57,10 @@ enum : int {
   GEMM_KTO_N = 1024,       // the K loop ends with the n-tile (k < n0 + 128): op(B)[k][n] = 0 for k > n
   GEMM_KTO_M = 2048,       // same with the m-tile (op(A)[m][k] = 0 for k > m)
   GEMM_C_MIRROR = 4096,    // off-diagonal tiles are also stored transposed (C symmetric, computed one-sided)
+  GEMM_DIAG_LOWER = 8192,  // K-contiguous kernels (GEMM3 / GEMM3'): in diagonal tiles only the 16x16 blocks on and below
+                           // the diagonal (m >= n) are computed and stored (the caller never reads the others)
+  GEMM_DIAG_UPPER = 16384, // same for n >= m (what GEMM_DIAG_LOWER becomes when gemm() transposes the problem)
+  GEMM_NO_SKIP = 32768,    // measurement only (option "gemm_no_skip"): compute every block of every tile
   GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower layout;
                            // the first kflat_nsd splits cover the diagonal blocks [0, kflat_diag), the
                            // others the strictly-lower blocks [kflat_diag, K)
@@ -117,6 +121,8 @@ struct GemmDesc {
   const int* kflat_ke = nullptr;
   long kflat_total = 0, kflat_diag = 0;
   int kflat_nsd = 0;
+  int tile_class = 0;      // 0 all tiles; 1 only tiles whose blocks are all computed; 2 only the tiles with skipped blocks
+                           // (edge tiles, GEMM_DIAG_* diagonal tiles) -- see get_tile_list
   int kstagger = 0;        // GEMM_KFLAT: workgroup (tm, tn) starts its K walk ((tm + tn) & 7) * kstagger chunks into
                            // its split and wraps around (see gemm_f64_kseg_lds_kernel)
 };

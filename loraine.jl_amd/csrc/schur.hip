@@ -286,7 +286,7 @@ __global__ void reduce_slabs_w_kernel(const double* __restrict__ slabs, long str
   long total = (long)M * N;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     int i = (int)(e % M), j = (int)(e / M);
-    if (i / TS < j / TS) continue;
+    if (i / 16 < j / 16) continue;          // (GEMM_DIAG_LOWER: blocks above the diagonal are not computed)
     double s1 = 0.0, s2 = 0.0;
     for (int k = 0; k < nslab; ++k) {
       const double v = slabs[(long)k * stride + e];
@@ -482,7 +482,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g1.B = Ut + off; g1.sBk = m; g1.sBn = 1; g1.bB = 0;     // op(B)[k][j] = L[k,j] = Ut[j + k*m]
       g1.C = P; g1.sCm = ldp; g1.sCn = 1; g1.bC = p_elems;
       g1.M = g1.K = m - c0; g1.N = c1 - c0; g1.batch = nb;
-      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N;
+      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
       LRN_TRY(gemm(c->stream, g1));
       toc(c, "gemm1");
       tic(c);
@@ -492,7 +492,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g2.C = T + (long)a * 16; g2.sCm = 1; g2.sCn = m; g2.bC = 16;
       g2.pk_cstride = cstride;
       g2.M = g2.K = m - c0; g2.N = c1 - c0; g2.batch = nb;
-      g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED;
+      g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
       g2.pk_m = m;
       g2.pk_off = c0;
       LRN_TRY(gemm(c->stream, g2));
@@ -515,6 +515,11 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
     long tiles = 0;
     const int tM = (M + TS - 1) / TS;
     for (int tn = 0; tn < tM; ++tn) tiles += tM - tn;
+    // GEMM3' runs as two launches: the regular tiles -- all equally long, lock-step through K -- and then the tiles
+    // with blocks to skip (diagonal tiles: blocks above the diagonal; the last tile row when nd % 128 != 0).  The
+    // split-K factor is chosen for the regular launch (the bulk of the work).
+    const bool two_launches = !c->opt.gemm_no_skip && tM > 2;
+    if (two_launches) tiles -= tM + ((M % TS) ? tM - 1 : 0);
     // chunk ranges of the runs and the split-K budget (see below) divided over them by length
     struct RunK { long d0, d1, o0, o1; int ks, nsd; };
     std::vector<RunK> rk;
@@ -589,13 +594,23 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g3.kflat_cstride = cstride;
       g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
       g3.M = M; g3.N = N;
-      g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT;
+      g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT | GEMM_DIAG_LOWER | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
       g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = 1;
       g3.kflat_kb = kb.data(); g3.kflat_ke = ke.data();
       g3.kstagger = c->opt.gemm3_stagger;
       g3.ksplit = nslab; g3.sCs = (long)M * N;
-      LRN_TRY(gemm(c->stream, g3));
-      toc(c, "gemm3");
+      if (two_launches) {
+        g3.tile_class = 1;
+        LRN_TRY(gemm(c->stream, g3));
+        toc(c, "gemm3");
+        tic(c);
+        g3.tile_class = 2;
+        LRN_TRY(gemm(c->stream, g3));
+        toc(c, "gemm3");                // (two launches of one kernel: lrn_get_count("gemm3") = 2 per assembly)
+      } else {
+        LRN_TRY(gemm(c->stream, g3));
+        toc(c, "gemm3");
+      }
     }
     tic(c);
     hipLaunchKernelGGL(reduce_slabs_w_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,
@@ -693,7 +708,7 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
       g1.B = Ut; g1.sBk = m; g1.sBn = 1; g1.bB = 0;
       g1.C = P; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
       g1.M = g1.N = g1.K = m; g1.batch = nb;
-      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N;
+      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
       LRN_TRY(gemm(c->stream, g1));
       GemmDesc g2;   // At = L' P, tiles i >= j (K from the tile's row origin), mirrored: full symmetric, col-major
       g2.A = Ut; g2.sAm = 1; g2.sAk = m; g2.bA = 0;

@@ -82,6 +82,7 @@ class MySolver:
         self._check_ranges()
         self.cg_iter_tot = 0
         self.dist = None                 # sharding.DistributedHotPath when run with one process per GPU
+        self.exact_regularised_solve = False   # True: (H + d I)^-1 h instead of the reference's double solve (:85,90)
         self.status = 0
         self.trace = []
         self.dev = device if device is not None else Device(device_index)
@@ -126,7 +127,6 @@ class MySolver:
         self.beta = np.zeros(m.nlmi)
         self.regcount = 0
         self.chol_is_object = False
-        self.exact_regularised_solve = False   # True: (H + d I)^-1 h instead of the reference's double solve
         if self.kit == 1:
             if m.nlmi == 0:
                 self._say("WARNING: Switching to a direct solver, no LMIs")
@@ -201,6 +201,9 @@ class MySolver:
         self.chol_is_object = False
         info = self.dev.schur_factor()
         if info == 0:
+            nb = self.dev.count("chol_boosted")
+            if nb:                                   # not the reference's behaviour: say so
+                self._say(f"H numerically singular: {nb} pivot(s) at rounding level boosted")
             return True
         self._say("Matrix H not positive definite, trying to regularize")
         self.regcount += 1
