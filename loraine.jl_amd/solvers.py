@@ -222,7 +222,7 @@ class MySolver:
         return False
 
     def _schur_solve(self, h):
-        """`cholBBBB' \ (cholBBBB \ h)` (src/predictor_corrector.jl:90,199) [GPU]; in a regularised iteration the
+        r"""`cholBBBB' \ (cholBBBB \ h)` (src/predictor_corrector.jl:90,199) [GPU]; in a regularised iteration the
         reference's operand is a Cholesky object and the expression is H_reg^-1 (H_reg^-1 h) -- reproduced unless the
         solver was created with exact_regularised_solve=True (divergences)."""
         x = self.dev.schur_solve(h)

@@ -116,3 +116,30 @@ def test_c3_thetaG11_operator_preconditioner_cg_on_golden_iterate(dev, prec_eig)
         # same number of steps of the same recurrence: the iterates differ by rounding only (measured 3e-8 at
         # tol 1e-6, 5e-14 at tol 1e-10)
         assert relerr(x, xs) < 0.1 * float(tol) + 1e-11
+
+
+def test_c3_thetaG11_whole_solve_against_the_oracle_trace():
+    """The C3 solve (PCG with H_alpha, erank 1, tolerance 1e-2 halved per iteration).  A TRUNCATED CG solve is not a
+    contraction: at these tolerances a perturbation of the iterate grows by two orders of magnitude per IP iteration
+    (tools/c3_divergence.py: 3e-12 -> 2e-10 -> 1e-8 -> 1e-4 in dely over the first three iterations; the oracle run
+    against ITSELF from an initial point perturbed by 1e-13 behaves the same, profiles/r02_c3_sensitivity.txt).  So
+    what two correct implementations share is: the hot-path results on identical inputs (test above, 1e-10..1e-13),
+    the first iterations of the trajectory to the north-star tolerance, the iteration count, and the optimum to the
+    termination tolerance eDIMACS = 1e-5."""
+    from loraine_jl_amd.optimizer import Optimizer
+    o = Optimizer(resident=True)
+    o.set_silent(True)
+    for k, v in dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5).items():
+        o.set_attribute(k, v)
+    o.read_from_file(os.path.join(GOLD, "thetaG11.dat-s"))
+    o.optimize()
+    tr = json.load(open(os.path.join(GOLD, "trace_thetaG11.json")))
+    assert o.solver.status == tr["status"] == 1 and o.solver.iter == tr["iterations"]
+    for k in range(2):                                   # before the sensitivity of the truncated solves takes over
+        t = o.solver.trace[k]
+        assert (t["cg_pre"], t["cg_cor"]) == (tr["cg_pre"][k], tr["cg_cor"][k])
+        assert t["primal_obj"] == pytest.approx(tr["primal"][k], rel=1e-8)
+        assert t["dual_obj"] == pytest.approx(tr["dual"][k], rel=1e-8)
+    assert o.objective_value() == pytest.approx(tr["objective"], rel=2e-6)
+    assert o.objective_value() == pytest.approx(400.0, rel=2e-6)                  # SDPLIB (external)
+    assert abs(o.solver.cg_iter_tot - tr["cg_total"]) <= 0.15 * tr["cg_total"]

@@ -171,3 +171,61 @@ def test_golden_iterate_fixture_is_reproducible():
     assert np.allclose(s.X[0], g["X"], rtol=1e-9, atol=1e-12) and np.allclose(s.y, g["y"], rtol=1e-9, atol=1e-12)
     H = lo.makeBBBBs(model.n, 1, model.A, model.AA, [g["W"]], model.qA, model.sigmaA)
     assert np.allclose(np.tril(H), g["H_lower"], rtol=1e-10, atol=1e-12)
+
+
+def _unpack_f32_lower(v, m):
+    M = np.zeros((m, m))
+    M[np.tril_indices(m)] = v.astype(np.float64)
+    return M + np.tril(M, -1).T
+
+
+def test_golden_c2_fixture_is_what_the_oracle_computes():
+    """tests/golden/iterate_maxG11.npz (oracle/make_golden.py): from the stored float32 iterate the oracle reproduces
+    the stored rank-one Schur matrix digests, right-hand side and solve -- rank-one and general assembly agreeing."""
+    import scipy.linalg as sla
+    g = np.load(os.path.join(GOLD, "iterate_maxG11.npz"))
+    model = lo.model_from_sdpa(os.path.join(GOLD, "maxG11.dat-s"), datarank=-1)
+    m = int(model.msizes[0])
+    s = lo.MySolver(model, dict(kit=0, datarank=-1, verb=0))
+    lo.setup_solver(s, lo.Halpha(0))
+    lo.initial_point(s)
+    s.X[0], s.S[0], s.y = _unpack_f32_lower(g["X_lower_f32"], m), _unpack_f32_lower(g["S_lower_f32"], m), g["y"].copy()
+    lo.find_mu(s)
+    lo.prepare_W(s)
+    assert np.allclose(np.sort(s.D[0]), g["D_sorted"], rtol=1e-10)
+    H = lo.makeBBBB_rank1(model.n, 1, model.B, s.G)
+    Hs = np.tril(H) + np.tril(H, -1).T
+    assert np.allclose(Hs @ g["probes"], g["H_probe"], rtol=1e-11, atol=1e-11 * np.abs(g["H_probe"]).max())
+    assert np.allclose(Hs[g["H_sample_i"], g["H_sample_j"]], g["H_sample"], rtol=1e-11, atol=1e-14 * np.abs(g["H_sample"]).max())
+    L = np.linalg.cholesky(Hs)
+    dely = sla.solve_triangular(L.T, sla.solve_triangular(L, g["h"], lower=True), lower=False)
+    assert np.allclose(dely, g["dely"], rtol=1e-8, atol=1e-10 * np.abs(g["dely"]).max())
+
+
+def test_golden_c3_fixture_is_what_the_oracle_computes():
+    """tests/golden/iterate_thetaG11.npz: MyA(x), MyM(x) and cg from the stored iterate (src/Solvers.jl:572-904)."""
+    g = np.load(os.path.join(GOLD, "iterate_thetaG11.npz"))
+    model = lo.model_from_sdpa(os.path.join(GOLD, "thetaG11.dat-s"))
+    m = int(model.msizes[0])
+    s = lo.MySolver(model, dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5, verb=0))
+    halpha = lo.Halpha(1)
+    lo.setup_solver(s, halpha)
+    lo.initial_point(s)
+    s.X[0], s.S[0], s.y = _unpack_f32_lower(g["X_lower_f32"], m), _unpack_f32_lower(g["S_lower_f32"], m), g["y"].copy()
+    lo.find_mu(s)
+    lo.prepare_W(s)
+    lo.Prec_for_CG_tilS_prep(s, halpha)
+    assert float(np.sqrt(halpha.AAAATtau.diagonal()[0])) == pytest.approx(float(g["tau"]), rel=1e-11)
+    U = halpha.Umat[0][:, 0]
+    assert np.allclose(U * np.sign(U[np.argmax(np.abs(U))]), g["Umat"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(halpha.Z[0] @ g["probes"], g["Z_probe"], rtol=1e-9, atol=1e-11)
+    A = lo.MyA(s.W, model.AA, 0, model.C_lin, None, None)
+    M = lo.MyM(model.AA, halpha.AAAATtau, halpha.Umat, halpha.Z, halpha.cholS)
+    Ax, Mx = np.zeros(model.n), np.zeros(model.n)
+    A(Ax, g["x"])
+    M(Mx, g["x"])
+    assert np.allclose(Ax, g["MyA_x"], rtol=1e-11, atol=1e-12 * np.abs(Ax).max())
+    assert np.allclose(Mx, g["MyM_x"], rtol=1e-9, atol=1e-11 * np.abs(Mx).max())
+    x, ec, it = lo.cg(A, g["h"], tol=float(g["cg_tols"][0]), maxIter=10000, precon=M)
+    assert (ec, it) == (int(g["cg_exit"][0]), int(g["cg_iters"][0]))
+    assert np.linalg.norm(x - g["cg_x"][0]) <= 1e-7 * np.linalg.norm(x)

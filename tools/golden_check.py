@@ -22,11 +22,14 @@ for prec_eig in (1, 0):
         print("  cg tol", tol, "oracle", int(ec), int(it), "gpu", exit_code, iters, "rel diff", relerr(x, xs))
     dev.close()
 from loraine_jl_amd.optimizer import Optimizer
-for name, opts in (("maxG11", dict(kit=0, datarank=-1)), ("thetaG11", dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5))):
+for name, opts, pe in (("maxG11", dict(kit=0, datarank=-1), 0), ("thetaG11", dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5), 0),
+                       ("thetaG11", dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5), 1)):
     f = os.path.join(GOLD, f"trace_{name}.json")
     if not os.path.exists(f): continue
     tr = json.load(open(f))
-    o = Optimizer(resident=True); o.set_silent(True)
+    d = loraine_jl_amd.Device(0); d.set_option("prec_eig", pe)
+    print("prec_eig", pe)
+    o = Optimizer(resident=True, device=d); o.set_silent(True)
     for k, v in opts.items(): o.set_attribute(k, v)
     o.read_from_file(os.path.join(GOLD, f"{name}.dat-s")); o.optimize()
     print(name, "iters", o.solver.iter, tr["iterations"], "obj", o.objective_value(), tr["objective"])
