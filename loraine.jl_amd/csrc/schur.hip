@@ -36,31 +36,45 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// one wavefront per entry (pi, pj >= pi), pi in [p_lo, p_hi)
+// LANES lanes per entry (pi, pj >= pi), pi in [p_lo, p_hi):
+//     H[i,j] = tr(A_i W A_j W) = sum_{(r,c) in A_i} sum_{(p,q) in A_j} a_rc b_pq W[c,p] W[q,r]
+// The kernel is bound by the chain of dependent loads of one entry (entry lists -> W gathers -> reduction), not by
+// gather bandwidth (rocprofv3, profiles/r02_sparse_*): what raises its throughput is entries in flight.  LANES = 64 for
+// long products; 16 (four entries per wavefront) when nnz_i * nnz_j is a few hundred at most.  W is symmetric: both
+// factors are fetched from the COLUMNS of the owner's support, W[p + c*msz] and W[q + r*msz] -- consecutive workgroups
+// share pi, so at msz = 10^4 (W = 800 MB) the gathers of an owner stay in a few 80 KB columns (L2-miss traffic of the
+// C5 assembly 234 GB -> 50 GB).  Staging the block W[supp_i, supp_j] in LDS was tried (one wave per entry, 8 KB each):
+// a fifth of the fabric traffic again but 32 KB of LDS per workgroup cost 12 of 32 waves per CU and the kernel got
+// slower (tru9 2.25 -> 2.75 ms, C5 110 -> 140 ms; profiles/r02_sparse_pair_lds_staged_summary.csv).
+template <int LANES>
 __global__ __launch_bounds__(256) void pair_wave_kernel(
     const long* __restrict__ ptr, const int* __restrict__ er, const int* __restrict__ ec,
     const double* __restrict__ ev, const double* __restrict__ W, int msz, int p_lo, int p_hi,
     int p_end, const int* __restrict__ hidx, double* __restrict__ H, int ldh, int rank, int world,
     int bs) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int PER_WG = 256 / LANES;
+  const int lane = threadIdx.x & (LANES - 1), grp = threadIdx.x / LANES;
   const int pi = p_lo + blockIdx.y;
   if (pi >= p_hi) return;
   if (world > 1 && shard_owner(pi / bs, world) != rank) return;
-  const int pj = pi + blockIdx.x * 4 + wv;
-  if (pj >= p_end) return;
-  const long ib = ptr[pi], jb = ptr[pj];
-  const int ni = (int)(ptr[pi + 1] - ib), nj = (int)(ptr[pj + 1] - jb);
-  const int total = ni * nj;
+  const int pj = pi + blockIdx.x * PER_WG + grp;
+  const bool live = pj < p_end;                 // (whole wavefronts stay together for the shuffles below)
   double acc = 0.0;
-  for (int idx = lane; idx < total; idx += 64) {
-    int e = idx / nj, f = idx - e * nj;
-    int r = er[ib + e], c = ec[ib + e];
-    int p = er[jb + f], q = ec[jb + f];
-    // A_i[r,c] W[c,p] A_j[p,q] W[q,r]
-    acc += ev[ib + e] * ev[jb + f] * W[(long)c + (long)p * msz] * W[(long)q + (long)r * msz];
+  if (live) {
+    const long ib = ptr[pi], jb = ptr[pj];
+    const int ni = (int)(ptr[pi + 1] - ib), nj = (int)(ptr[pj + 1] - jb);
+    const int total = ni * nj;
+    for (int idx = lane; idx < total; idx += LANES) {
+      int e = idx / nj, f = idx - e * nj;
+      int r = er[ib + e], c = ec[ib + e];
+      int p = er[jb + f], q = ec[jb + f];
+      // A_i[r,c] W[c,p] A_j[p,q] W[q,r]
+      acc += ev[ib + e] * ev[jb + f] * W[(long)p + (long)c * msz] * W[(long)q + (long)r * msz];
+    }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) {
+#pragma unroll
+  for (int off = LANES / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LANES);
+  if (live && lane == 0) {
     int hi = hidx[pi], hj = hidx[pj];
     int rr = hi > hj ? hi : hj, cc = hi > hj ? hj : hi;
     H[(long)rr + (long)cc * ldh] += acc;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void pair_thread_kernel(
     double a = ev[ib + e];
     for (int f = 0; f < nj; ++f) {
       int p = er[jb + f], q = ec[jb + f];
-      acc += a * ev[jb + f] * W[(long)c + (long)p * msz] * W[(long)q + (long)r * msz];
+      acc += a * ev[jb + f] * W[(long)p + (long)c * msz] * W[(long)q + (long)r * msz];   // both from columns of A_i
     }
   }
   int hi = hidx[pi], hj = hidx[pj];
@@ -812,12 +826,25 @@ static int assemble_sparse(lrn_ctx* c, LmiBlock& b) {
   if (b.q_wave > b.nd) {
     int nown = b.q_wave - b.nd;
     int noth = b.npos_nz - b.nd;
+    // entries per wavefront by the typical product length: mean nnz of the sparse owners squared
+    double mean_nnz = 0.0;
+    for (int p = b.nd; p < b.npos_nz; ++p) mean_nnz += (double)b.nnz[p];
+    mean_nnz /= std::max(1, b.npos_nz - b.nd);
+    int lanes = c->opt.pair_lanes;
+    if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 64) lanes = mean_nnz * mean_nnz <= 512.0 ? 16 : 64;
+    const int per_wg = 256 / lanes;
     for (int y0 = 0; y0 < nown; y0 += 32768) {
       int ny = std::min(32768, nown - y0);
-      hipLaunchKernelGGL(pair_wave_kernel, dim3((noth - y0 + 3) / 4, ny), dim3(256), 0, c->stream,
-                         b.ent_ptr.as<long>(), b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(),
-                         b.W.as<double>(), b.msz, b.nd + y0, b.q_wave, b.npos_nz, b.hidx.as<int>(), H, n,
-                         c->rank, c->world, c->shard_bs);
+      dim3 grid((noth - y0 + per_wg - 1) / per_wg, ny);
+#define LRN_PAIR_LAUNCH(L)                                                                                           \
+  hipLaunchKernelGGL(pair_wave_kernel<L>, grid, dim3(256), 0, c->stream, b.ent_ptr.as<long>(), b.ent_r.as<int>(),   \
+                     b.ent_c.as<int>(), b.ent_v.as<double>(), b.W.as<double>(), b.msz, b.nd + y0, b.q_wave,          \
+                     b.npos_nz, b.hidx.as<int>(), H, n, c->rank, c->world, c->shard_bs)
+      if (lanes == 4) LRN_PAIR_LAUNCH(4);
+      else if (lanes == 8) LRN_PAIR_LAUNCH(8);
+      else if (lanes == 16) LRN_PAIR_LAUNCH(16);
+      else LRN_PAIR_LAUNCH(64);
+#undef LRN_PAIR_LAUNCH
     }
   }
   if (b.npos_nz > b.q_wave) {
