@@ -241,55 +241,9 @@ __device__ __forceinline__ void load_diag_block(const double* __restrict__ L, in
   }
 }
 
-// forward step for block b:  y_b = L_kk^-1 r_b ; r[i] -= L[i, b] * y_b for i > block b
-__global__ __launch_bounds__(256) void trsv_fwd_step(const double* __restrict__ L, int ld, int n,
-                                                     const double* __restrict__ Linv, int k0, int nb,
-                                                     double* __restrict__ r, double* __restrict__ y) {
-  __shared__ double lb[NB][NB + 1];
-  __shared__ double yb[NB];
-  const int t = threadIdx.x;
-  load_diag_block(L, ld, k0, nb, lb, 256);
-  if (t < NB) yb[t] = t < nb ? r[k0 + t] : 0.0;
-  __syncthreads();
-  if (t < 64) block_subst_wave(lb, yb, nb, false);
-  __syncthreads();
-  if (blockIdx.x == 0 && t < nb) y[k0 + t] = yb[t];
-  int row = k0 + nb + blockIdx.x * 256 + t;
-  if (row < n) {
-    double s = 0.0;
-    const double* Lr = L + row + (long)k0 * ld;
-#pragma unroll 8
-    for (int c = 0; c < nb; ++c) s += Lr[(long)c * ld] * yb[c];
-    r[row] -= s;
-  }
-}
-
-// backward step for block b:  x_b = L_kk^-T r_b ; r[c] -= sum_i L[k0+i, c] x_b[i], c < k0
-__global__ __launch_bounds__(256) void trsv_bwd_step(const double* __restrict__ L, int ld, int n,
-                                                     const double* __restrict__ Linv, int k0, int nb,
-                                                     double* __restrict__ r, double* __restrict__ x) {
-  __shared__ double lb[NB][NB + 1];
-  __shared__ double xb[NB];
-  const int t = threadIdx.x;
-  load_diag_block(L, ld, k0, nb, lb, 256);
-  if (t < NB) xb[t] = t < nb ? r[k0 + t] : 0.0;
-  __syncthreads();
-  if (t < 64) block_subst_wave(lb, xb, nb, true);
-  __syncthreads();
-  if (blockIdx.x == 0 && t < nb) x[k0 + t] = xb[t];
-  int c = blockIdx.x * 256 + t;
-  if (c < k0) {
-    const double* Lc = L + k0 + (long)c * ld;
-    double s = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < nb; ++i) s += Lc[i] * xb[i];
-    r[c] -= s;
-  }
-}
-
 // whole L^-T L^-1 h in ONE workgroup (n <= POTRS_SMALL): 2*nblk dependent block steps without
 // launch gaps; the right-hand side lives in LDS.
-static constexpr int POTRS_SMALL = 2048;
+static constexpr int POTRS_SMALL = 512;       // (above it the super-block kernels below win: n = 801 357 -> ~180 us)
 __global__ __launch_bounds__(1024) void potrs_small_kernel(const double* __restrict__ L, int ld, int n,
                                                            const double* __restrict__ Linv,
                                                            const double* __restrict__ h, double* __restrict__ x) {
@@ -338,27 +292,243 @@ __global__ __launch_bounds__(1024) void potrs_small_kernel(const double* __restr
   for (int i = t; i < n; i += 1024) x[i] = r[i];
 }
 
-// x = L^{-T} L^{-1} h ; r is scratch (n doubles); x may alias h? no: h is read-only.
+// ------------------------------------------------------------------ triangular solves (vector), n > POTRS_SMALL
+// Super-blocks of SB = 256 rows, one launch per super-block and direction (n = 4000: 16 + 16 launches per
+// L'\(L\h) where the 64-row stepping took 126).  Launch b of the forward solve:
+//   workgroup 0   subtracts the previous super-block's contribution from ITS 256 rows (a 256 x 256 mat-vec over 16
+//                 waves), then solves the 256 x 256 diagonal block: four 64 x 64 substitutions, each by ONE wavefront
+//                 with its row of the block in registers (no LDS traffic, no division: x_c = r_c * (1 / l_cc) travels
+//                 by v_readlane), interleaved with the in-block updates by all 16 waves;
+//   workgroups 1+ subtract the previous super-block's contribution from the rows further down (256 rows each).
+// The chain of dependent work per launch is workgroup 0's; everything else overlaps with it.  The backward solve
+// mirrors this on columns (dot products down the columns, one wavefront per column: coalesced) with the diagonal
+// blocks transposed through LDS so that the same readlane substitution applies.  Substitution through the blocks
+// themselves -- no inverted blocks (see the header of this file).
+static constexpr int SB = 256;
+
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+static constexpr int TRSV_T = 512;      // 8 wavefronts: 2 per SIMD, so a wave may keep its 64 x 64 block row in registers
+
+__global__ __launch_bounds__(TRSV_T) void trsv_fwd_sb_kernel(const double* __restrict__ L, int ld, int n, int k0,
+                                                             double* __restrict__ r, double* __restrict__ y) {
+  __shared__ double xs[SB];          // x of the previous super-block
+  __shared__ double xc[SB];          // x of this one, sub-block by sub-block
+  __shared__ double part[2][SB];
+  const int t = threadIdx.x, rr = t & (SB - 1), cg = t >> 8;       // row in the block, half of the columns
+  const int kp = k0 - SB;
+  const int row = (blockIdx.x == 0 ? k0 : k0 + SB + ((int)blockIdx.x - 1) * SB) + rr;
+  const int lane = t & 63, w = t >> 6;
+  // workgroup 0, waves 0..3: the wave's own 64 x 64 diagonal block row, in flight under the mat-vec below
+  double a[64];
+  double rinv = 1.0;
+  if (blockIdx.x == 0 && t < SB) {
+    const int c0 = k0 + 64 * w;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) a[c] = (c < lane && row < n) ? L[row + (long)(c0 + c) * ld] : 0.0;   // strictly lower part
+    rinv = row < n ? 1.0 / L[row + (long)row * ld] : 1.0;
+  }
+  if (k0 > 0 && t < SB) xs[t] = y[kp + t];
+  __syncthreads();
+  double s = 0.0;
+  if (k0 > 0 && row < n) {
+    const double* Lr = L + row + (long)(kp + cg * 128) * ld;
+    const double* xq = xs + cg * 128;
+    // one CU streams this 256 x 256 block: what bounds it is bytes in flight -- 32 independent loads per lane
+#pragma unroll
+    for (int c8 = 0; c8 < 128; c8 += 32) {
+      double v[32];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) v[c] = Lr[(long)(c8 + c) * ld];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) s += v[c] * xq[c8 + c];
+    }
+  }
+  part[cg][rr] = s;
+  __syncthreads();
+  if (blockIdx.x > 0) {
+    if (cg == 0 && row < n) r[row] -= part[0][rr] + part[1][rr];
+    return;
+  }
+  double rt = 0.0;
+  if (t < SB && row < n) rt = r[row] - (part[0][rr] + part[1][rr]);
+  for (int sb = 0; sb < 4; ++sb) {
+    const int c0 = k0 + 64 * sb;
+    __syncthreads();                 // part[] free again
+    if (w == sb) {
+      // lane i ends with r_i - sum_{c<i} l_ic x_c (a[c] = 0 for c >= i: no compares in the chain); x_c = that / l_cc is
+      // complete in lane c when step c broadcasts it
+#pragma unroll
+      for (int c = 0; c < 64; ++c) rt -= a[c] * readlane_f64(rt * rinv, c);
+      rt *= rinv;
+      xc[64 * sb + lane] = rt;
+      if (row < n) y[row] = rt;
+    }
+    __syncthreads();
+    // rows of the later sub-blocks: 32 columns per half
+    double u = 0.0;
+    if (rr >= 64 * (sb + 1) && row < n) {
+      const double* Lr = L + row + (long)(c0 + cg * 32) * ld;
+      const double* xq = xc + 64 * sb + cg * 32;
+      double v[32];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) v[c] = Lr[(long)c * ld];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) u += v[c] * xq[c];
+    }
+    part[cg][rr] = u;
+    __syncthreads();
+    if (t < SB && rr >= 64 * (sb + 1)) rt -= part[0][rr] + part[1][rr];
+  }
+}
+
+__device__ __forceinline__ double wave_allsum64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sums of 8 per-lane values over the wavefront in 10 shuffles instead of 48: three exchange steps halve the values a
+// lane carries (8 -> 4 -> 2 -> 1) while folding lane bits 5, 4, 3, three more fold bits 2, 1, 0.  Returns, in every lane,
+// the wave-wide sum of p[(lane >> 3) & 7].
+__device__ __forceinline__ double wave_sum8(const double (&p)[8], int lane) {
+  double q4[4], q2[2];
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q4[k] = (b5 ? p[k + 4] : p[k]) + __shfl_xor(b5 ? p[k] : p[k + 4], 32, 64);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) q2[k] = (b4 ? q4[k + 2] : q4[k]) + __shfl_xor(b4 ? q4[k] : q4[k + 2], 16, 64);
+  double v = (b3 ? q2[1] : q2[0]) + __shfl_xor(b3 ? q2[0] : q2[1], 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(TRSV_T) void trsv_bwd_sb_kernel(const double* __restrict__ L, int ld, int n, int k0,
+                                                             double* __restrict__ r, double* __restrict__ x) {
+  __shared__ double xn[SB];          // x of the NEXT super-block (rows k0 + SB ...), final
+  __shared__ double xc[SB];          // x of this one
+  __shared__ double upd[SB];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;       // 8 wavefronts
+  constexpr int NW = TRSV_T / 64;
+  const int k1 = k0 + SB;
+  const int nn = n - k1 < 0 ? 0 : (n - k1 > SB ? SB : n - k1);
+  // workgroup 0, waves 0..3: lane k of wave s takes COLUMN k of diagonal block s (strictly lower part), so that
+  // L' x = r is the same broadcast-and-subtract chain as the forward solve.  The loads are strided across the lanes
+  // (each instruction touches 64 lines, all of which later instructions reuse from L1); issued first, they are in
+  // flight under the dot products below.
+  double b[64];
+  double rinv = 1.0;
+  if (blockIdx.x == 0 && t < SB) {
+    const int col = k0 + t;
+    const int c0 = k0 + 64 * w;
+#pragma unroll
+    for (int rw = 0; rw < 64; ++rw) b[rw] = (rw > lane && c0 + rw < n) ? L[(long)(c0 + rw) + (long)col * ld] : 0.0;
+    rinv = col < n ? 1.0 / L[(long)col + (long)col * ld] : 1.0;
+  }
+  if (t < SB) xn[t] = t < nn ? x[k1 + t] : 0.0;
+  __syncthreads();
+  // dots of the columns col0 .. col0 + 7 (those < cend) with x of the next super-block, by one wavefront: the 32
+  // loads of the batch are all issued before the first is used (the loads, not the arithmetic, are the time);
+  // returns the dot of column col0 + j in the lanes 8 j .. 8 j + 7
+  auto dots8 = [&](int col0, int cend) -> double {
+    double v[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        v[j][q] = (col0 + j < cend && i < nn) ? L[(long)(k1 + i) + (long)(col0 + j) * ld] : 0.0;
+      }
+    double pj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pj[j] = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pj[j] += v[j][q] * xn[lane + 64 * q];
+    }
+    return wave_sum8(pj, lane);
+  };
+  if (blockIdx.x > 0) {                                       // columns before this super-block, 64 per workgroup
+    const int col0 = ((int)blockIdx.x - 1) * (8 * NW) + 8 * w;
+    if (col0 < k0 && nn > 0) {
+      const double d = dots8(col0, k0);
+      if ((lane & 7) == 0 && col0 + (lane >> 3) < k0) r[col0 + (lane >> 3)] -= d;
+    }
+    return;
+  }
+  for (int j8 = 0; j8 < SB / NW; j8 += 8) {                   // the columns of this super-block, 32 per wavefront
+    const int cc0 = w * (SB / NW) + j8;
+    const double d = nn > 0 ? dots8(k0 + cc0, n) : 0.0;
+    const int cj = cc0 + (lane >> 3);
+    if ((lane & 7) == 0) upd[cj] = (k0 + cj < n ? r[k0 + cj] : 0.0) - d;
+  }
+  __syncthreads();
+  double rt = t < SB ? upd[t] : 0.0;                          // thread t < 256 owns column k0 + t
+  for (int sb = 3; sb >= 0; --sb) {
+    const int c0 = k0 + 64 * sb;
+    __syncthreads();                                          // upd[] read
+    if (w == sb) {
+#pragma unroll
+      for (int c = 63; c >= 0; --c) rt -= b[c] * readlane_f64(rt * rinv, c);
+      rt *= rinv;
+      xc[64 * sb + lane] = rt;
+      if (c0 + lane < n) x[c0 + lane] = rt;
+    }
+    __syncthreads();
+    // earlier columns of the super-block: dot over the 64 rows of sub-block sb, one wavefront per column; a wave's
+    // columns cc = w, w + 8, ... (at most 24): all loads first
+    if (sb > 0) {
+      const double xl = (c0 + lane < n) ? xc[64 * sb + lane] : 0.0;
+      double v[24];
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        const int cc = w + NW * q;
+        v[q] = (cc < 64 * sb && c0 + lane < n) ? L[(long)(c0 + lane) + (long)(k0 + cc) * ld] : 0.0;
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        if (w + NW * 8 * g < 64 * sb) {                       // wave-uniform: this group of 8 has live columns
+          double pj[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pj[j] = v[8 * g + j] * xl;
+          const double sq = wave_sum8(pj, lane);
+          const int cc = w + NW * (8 * g + (lane >> 3));
+          if ((lane & 7) == 0 && cc < 64 * sb) upd[cc] = sq;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < 64 * sb) rt -= upd[t];
+  }
+}
+
+// x = L^{-T} L^{-1} h ; r, y: scratch (n doubles each); h is read-only.
 int potrs_vec(hipStream_t st, const double* L, int n, int ld, const double* Linv, const double* h,
               double* x, double* r, double* y) {
+  (void)Linv;
   if (n <= POTRS_SMALL) {
     hipLaunchKernelGGL(potrs_small_kernel, dim3(1), dim3(1024), 0, st, L, ld, n, Linv, h, x);
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   hipMemcpyAsync(r, h, (size_t)n * 8, hipMemcpyDeviceToDevice, st);
-  int nblk = (n + NB - 1) / NB;
-  for (int b = 0; b < nblk; ++b) {
-    int k0 = b * NB, nb = n - k0 < NB ? n - k0 : NB;
-    int rem = n - k0 - nb;
-    unsigned blocks = rem > 0 ? (unsigned)((rem + 255) / 256) : 1u;
-    hipLaunchKernelGGL(trsv_fwd_step, dim3(blocks), dim3(256), 0, st, L, ld, n,
-                       Linv + (long)b * NB * NB, k0, nb, r, y);
+  const int nsb = (n + SB - 1) / SB;
+  for (int b = 0; b < nsb; ++b) {
+    const int k0 = b * SB;
+    const int below = n - k0 - SB;                            // rows further down (they take x of super-block b - 1)
+    const unsigned wgs = 1u + (b > 0 && below > 0 ? (unsigned)((below + SB - 1) / SB) : 0u);
+    hipLaunchKernelGGL(trsv_fwd_sb_kernel, dim3(wgs), dim3(TRSV_T), 0, st, L, ld, n, k0, r, y);
   }
-  for (int b = nblk - 1; b >= 0; --b) {
-    int k0 = b * NB, nb = n - k0 < NB ? n - k0 : NB;
-    unsigned blocks = k0 > 0 ? (unsigned)((k0 + 255) / 256) : 1u;
-    hipLaunchKernelGGL(trsv_bwd_step, dim3(blocks), dim3(256), 0, st, L, ld, n,
-                       Linv + (long)b * NB * NB, k0, nb, y, x);
+  for (int b = nsb - 1; b >= 0; --b) {
+    const int k0 = b * SB;
+    const bool have_next = k0 + SB < n;
+    const unsigned wgs = 1u + (have_next && k0 > 0 ? (unsigned)((k0 + 63) / 64) : 0u);      // 64 columns per workgroup
+    hipLaunchKernelGGL(trsv_bwd_sb_kernel, dim3(wgs), dim3(TRSV_T), 0, st, L, ld, n, k0, y, x);
   }
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }

@@ -130,6 +130,22 @@ def test_potrf_potrs(dev, n):
     assert relerr(A @ x, b) < 1e-10
 
 
+@pytest.mark.parametrize("n", [513, 801, 1024, 2049, 2112, 2305, 3000, 4000])
+def test_potrs_superblock_path(dev, n):
+    """n > 512: the triangular solves run in 256-row super-blocks (one launch each, wave-level substitution through the
+    64 x 64 diagonal blocks): sizes with a full, a 64-aligned and a ragged last super-block, against LAPACK."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(n)
+    Mx = rng.standard_normal((n, n + 3))
+    A = Mx @ Mx.T + n * 1e-3 * np.eye(n)
+    b = rng.standard_normal(n)
+    x, info = dev.dbg_potrs(A, b)
+    assert info == 0
+    xref = sla.cho_solve(sla.cho_factor(A, lower=True), b)
+    assert relerr(x, xref) < 1e-9
+    assert relerr(A @ x, b) < 1e-10
+
+
 def test_potrf_reports_not_pd(dev):
     rng = np.random.default_rng(3)
     n = 200
