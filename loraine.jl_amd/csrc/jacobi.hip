@@ -230,8 +230,13 @@ __device__ __forceinline__ bool jrot(double al, double be, double ga, double tol
 // J = diag of the step's 2x2 rotations, G' = J'GJ decomposes into 256 independent 2x2 blocks
 // (pair k1 x pair k2) -> one thread per block, every thread recomputes the two rotations it
 // needs from the diagonal blocks, G is double-buffered: ONE barrier per step.
+// `full` = 0: only the 256 CROSS pairs (p in block I, q in block J) in 16 steps, pair k of step s = (k, 16 + (k + s) % 16).
+// The within-block pairs were made orthogonal when the block last met a partner with a full sweep; the driver asks
+// for the full schedule in round 0 of every sweep, where each block occurs once -- so a sweep still visits every
+// column pair once, at about half the dependent steps (the latency of this kernel is the round's time at msz ~ 1000).
 __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict__ Gpart, int nchunk, int n, int nbk2,
-                                                        int round, double tol, int inner, double* __restrict__ Rbuf,
+                                                        int round, double tol, int inner, int full,
+                                                        double* __restrict__ Rbuf,
                                                         int* __restrict__ flags, int* __restrict__ nrot) {
   __shared__ double G[2][32][33];
   __shared__ double R[32][33];
@@ -245,9 +250,11 @@ __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict
     return;
   }
   if (t == 0) anyrot = 0;
-  for (int e = t; e < 31 * 16; e += 256) {
+  const int nsteps = full ? 31 : 16;
+  for (int e = t; e < nsteps * 16; e += 256) {
     int p, q;
-    rr_pair(32, e >> 4, e & 15, &p, &q);
+    if (full) rr_pair(32, e >> 4, e & 15, &p, &q);
+    else { p = e & 15; q = 16 + (((e & 15) + (e >> 4)) & 15); }
     sched[e >> 4][e & 15][0] = (unsigned char)p;
     sched[e >> 4][e & 15][1] = (unsigned char)q;
   }
@@ -270,8 +277,8 @@ __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict
   int cur = 0;
   bool rotated = false;
   // inner > 1: further sweeps on the same Gram matrix (cheap next to streaming the panels at large n)
-  for (int istep = 0; istep < 31 * inner; ++istep) {
-    const int step = istep % 31;
+  for (int istep = 0; istep < nsteps * inner; ++istep) {
+    const int step = istep % nsteps;
     const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
     const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
     // one rotation per thread (pair k2); the row pair's (k1) comes from the lane of this wave whose
@@ -626,7 +633,7 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
         } else {
           hipLaunchKernelGGL(jb_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
           hipLaunchKernelGGL(jb_rotate_kernel, dim3(npair), dim3(256), 0, st, Gpart, nchunk, n, nbk2, round, tol,
-                             inner, Rbuf, flags, cnt);
+                             inner, (round == 0 || c->opt.jacobi_cross == 0) ? 1 : 0, Rbuf, flags, cnt);
           hipLaunchKernelGGL(jb_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
                              Rbuf, flags);
         }

@@ -13,7 +13,8 @@ t = time.perf_counter()
 for _ in range(2000): dev.schur_add_diag(0.0)
 import torch; torch.cuda.synchronize()
 print("add_diag call: %.1f us" % ((time.perf_counter() - t) / 2000 * 1e6))
-for n in (800, 2000):
+for n, cross in ((800, 0), (800, 1), (2000, 0), (2000, 1), (3000, 0), (3000, 1)):
+    dev.set_option("jacobi_cross", cross)
     rng = np.random.default_rng(n)
     Mx = rng.standard_normal((n, n)) @ np.diag(np.logspace(0, -4, n)) @ rng.standard_normal((n, n))
     for rep in range(2):
@@ -21,4 +22,4 @@ for n in (800, 2000):
         US, s, V, sw = dev.dbg_svd_jacobi(Mx)
         dt = time.perf_counter() - t
     sref = np.linalg.svd(Mx, compute_uv=False)
-    print(f"n={n} sweeps={sw} wall={dt*1e3:.1f} ms  sv relerr={np.max(np.abs(np.sort(s)[::-1]-sref)/sref):.2e}", flush=True)
+    print(f"n={n} cross={cross} sweeps={sw} wall={dt*1e3:.1f} ms  sv relerr={np.max(np.abs(np.sort(s)[::-1]-sref)/sref):.2e}", flush=True)
