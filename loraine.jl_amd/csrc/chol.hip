@@ -43,18 +43,27 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 __global__ __launch_bounds__(64) void potrf_diag_wave_kernel(double* __restrict__ A, int ld, int nb, int col0,
                                                              int* __restrict__ info, const double* __restrict__ diag0,
                                                              double boost, int max_boost) {
+  // column j of the factor, as it is produced: written once by the wave and read back by every lane as LDS
+  // broadcasts (uniform address) -- the rank-one update a[k] -= l_ij l_kj needs l_kj of lane k in every lane, and 2016
+  // such values per block through v_readlane (two per value, one SGPR pair, a wait state each) cost more (41 -> 38 us
+  // per block; 63 blocks per factorisation of the C4 Schur matrix.  The 64 columns as ONE basic block with selects
+  // instead of the per-column branches: 164 us -- the scheduler hoists the reads and spills).  One wave: its LDS
+  // operations execute in order, no barrier.
+  __shared__ double colbuf[2][NB];
   const int i = threadIdx.x;
   if (*info != 0) return;
   double a[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) a[j] = (i < nb && j < nb && i >= j) ? A[(long)i + (long)j * ld] : (i == j ? 1.0 : 0.0);
+  double d0v = 1.0;                              // lane j: original diagonal entry of column col0 + j (pivot boosting)
+  if (diag0 && i < nb) d0v = diag0[col0 + i];
   int bad = 0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     if (bad == 0) {
       double piv = readlane_f64(a[j], j);
       if (diag0 && j < nb) {
-        const double d0 = diag0[col0 + j];
+        const double d0 = readlane_f64(d0v, j);
         // d0 > 0: a structurally empty row (a variable that occurs in no constraint) is not rounding noise;
         // it fails like in the reference, whose +1e-4 I loop and regularisation count then decide
         if (d0 > 0.0 && piv <= boost * d0 && piv == piv) {
@@ -67,11 +76,14 @@ __global__ __launch_bounds__(64) void potrf_diag_wave_kernel(double* __restrict_
       }
       if (!(piv > 0.0)) bad = col0 + j + 1;        // also catches NaN; wave-uniform
       if (bad == 0) {
-        const double rl = 1.0 / sqrt(piv);
+        const double sq = sqrt(piv);
+        const double rl = 1.0 / sq;
         const double lij = a[j] * rl;
-        a[j] = (i == j) ? sqrt(piv) : lij;
+        a[j] = (i == j) ? sq : lij;
+        double* cb = colbuf[j & 1];
+        cb[i] = lij;
 #pragma unroll
-        for (int k = j + 1; k < NB; ++k) a[k] -= lij * readlane_f64(lij, k);
+        for (int k = j + 1; k < NB; ++k) a[k] -= lij * cb[k];
       }
     }
   }
