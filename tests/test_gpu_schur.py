@@ -488,3 +488,65 @@ def test_auto_mode_keeps_column_blocks_when_ranks_outnumber_tiles(dev):
         assert dev.schur_is_partial_sum() and dev.count("schur_chol") == 1
     finally:
         dev.set_shard(0, 1)
+
+
+@pytest.mark.parametrize("msz,nvar", [(300, 150), (1000, 300), (520, 260)])
+def test_block_masks_do_not_change_the_schur_matrix(dev, msz, nvar):
+    """Round 2: GEMM1'/2'/3' skip the 16x16 blocks that are zero, beyond the edges or never read (interleaved block
+    ownership + per-wave masks, GEMM3' as regular and short launches).  Skipped work contributes exact zeros or unread
+    entries: with option gemm_no_skip = 1 (every block of every tile computed, one GEMM3' launch) the lower triangle must
+    come out the same -- bit for bit where no summation order changed, 1e-14 otherwise -- and equal the definition."""
+    dev.synthetic_dense_model(msz, nvar, 31)
+    W, G = _spd(msz, 32, cond=1e5)
+    dev.set_scaling(0, W, G)
+    dev.set_option("schur_chol", 1)
+    try:
+        dev.reset_timing()
+        H1 = np.tril(dev.schur_assemble(0, want_H=True))
+        assert dev.count("schur_chol") == 1
+        dev.set_option("gemm_no_skip", 1)
+        H0 = np.tril(dev.schur_assemble(0, want_H=True))
+    finally:
+        dev.set_option("gemm_no_skip", 0)
+        dev.set_option("schur_chol", -1)
+    assert relerr(H1, H0) < 1e-14
+    A = np.stack([dev.get_constraint(0, k) for k in range(min(nvar, 12))])
+    Href = _brute_H(A, W)
+    assert relerr(H1[:12, :12], np.tril(Href)) < 1e-13
+
+
+def test_pair_kernel_lane_widths_agree(dev):
+    """pair_wave_kernel<16> (four Schur entries per wavefront, the default for short products) and <64> (one): the same
+    terms in another association -- equal to 1e-14 -- on theta1 (103 two-entry constraints and one of 50 entries, all
+    through the pair path with kappa = 1000)."""
+    import loraine_jl_amd  # noqa: F401
+    model = lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"), kappa=1000)
+    _upload(dev, model)
+    W, G = _spd(50, 9)
+    dev.set_scaling(0, W, G)
+    Hs = {}
+    try:
+        for lanes in (64, 16, 8, 4):
+            dev.set_option("pair_lanes", lanes)
+            Hs[lanes] = np.tril(dev.schur_assemble(0, want_H=True))
+    finally:
+        dev.set_option("pair_lanes", 0)
+    Href = lo.makeBBBBs(model.n, 1, model.A, model.AA, [W], model.qA, model.sigmaA)
+    for lanes, H in Hs.items():
+        assert relerr(H, Hs[64]) < 1e-14
+        assert relerr(H, np.tril(Href)) < 1e-13
+
+
+def test_reference_timer_names_are_aliases(dev):
+    """lrn_get_timing answers to the reference's TimerOutputs section names (src/makeBBBB.jl:86-98, :30)."""
+    dev.synthetic_dense_model(300, 64, 5)
+    W, G = _spd(300, 6)
+    dev.set_scaling(0, W, G)
+    dev.set_option("profile", 1)
+    dev.reset_timing()
+    dev.schur_assemble(0)
+    assert dev.timing("BBBBone1") == dev.timing("gemm1") > 0
+    assert dev.timing("BBBBone2") == dev.timing("gemm2") > 0
+    assert dev.timing("BBBBone3") == pytest.approx(dev.timing("gemm3") + dev.timing("reduce3"))
+    assert dev.timing("BBBBone4") == 0.0
+    assert dev.timing("BBBBs") == dev.timing("assemble") >= dev.timing("BBBBone")

@@ -127,3 +127,21 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_bench_dense_instance_is_the_oracles_model():
+    """bench.py feeds the oracle a dense instance built without the oracle's (slow, per-entry) model builder: AA, sigmaA
+    and qA must be exactly what `make_model` produces (src/model.jl:120-229), and the bounded constraint loop
+    (`ii_stop`) must compute the first columns of the full Schur matrix."""
+    import bench
+    msz, nvar = 40, 30
+    rows, AA, sigmaA, qA, rng = bench._dense_instance(msz, nvar, 3)
+    A = [[sp.csc_matrix((msz, msz))] + [sp.csc_matrix(rows[k].reshape(msz, msz)) for k in range(nvar)]]
+    model = lo.make_model(A, np.zeros(nvar), 0.0, None, None)
+    assert abs(model.AA[0] - AA).max() == 0
+    assert np.array_equal(model.sigmaA, sigmaA) and np.array_equal(model.qA, qA)
+    W, _ = bench.make_scaling(msz, 4)
+    H = lo.makeBBBBs(nvar, 1, model.A, model.AA, [W], model.qA, model.sigmaA)
+    Hs = lo.makeBBBBsi(0, bench._DenseRows(rows, msz), AA, W, nvar, qA, sigmaA, ii_stop=7)
+    assert np.array_equal(Hs[:, :7], H[:, :7])
+    assert np.count_nonzero(Hs[7:, 7:]) == 0                       # nothing beyond the sampled constraints
