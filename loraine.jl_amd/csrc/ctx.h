@@ -69,6 +69,8 @@ struct LrnOptions {
                                   // Schur column blocks, 1 all-reduce of partial sums); see lrn_schur_plan
   int gemm3_ksplit = 0;           // split-K factor of GEMM3 / GEMM3' (0 = auto)
   int gemm_no_skip = 0;           // measurement only: GEMM1'/2'/3' compute every 16x16 block (GEMM_NO_SKIP)
+  int gemm3_sched = 1;            // 1: one launch, regular tiles of every split first, short tiles last; 0: two launches
+  int gemm3_tile = 0;             // workgroup tile of GEMM3': 0 auto, 128, 160
   int gemm3_stagger = 0;          // K-walk stagger of GEMM3' in chunks of 16 (GemmDesc::kstagger)
   int svd_sdc = 0, sdc_min = 4000, sdc_leaf = 768;
   double sdc_l0 = 1e-6;

@@ -37,6 +37,11 @@ struct GemmParams {
   int kcols[MAX_KSPLIT + 1];     // KSEG: column range per split; KFLAT: first chunk of split s
   int kcols2[MAX_KSPLIT + 1];    // KFLAT: end chunk of split s
   const int2* tile_list;         // (tm, tn) per workgroup, super-tile order
+  // tile_class 3 (K-contiguous kernels): ONE launch walks the regular tiles of every split first and the tiles with
+  // skipped blocks (tile_list2) last -- a 1-D grid in which XCD x = blockIdx.x % 8 takes entries [x q1, (x+1) q1) of
+  // tile_list for split 0, 1, ... and then [x q2, (x+1) q2) of tile_list2 for split 0, 1, ...
+  const int2* tile_list2;
+  int n1, n2;                    // list lengths (multiples of 8); n2 < 0: the plain (tile, split) grid
 };
 
 #define MFMA_F64_ROW(lane, r) (((lane) >> 4) + 4 * (r))
@@ -480,24 +485,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
 // M/N are clamped to the last valid row (their results are never stored).
 // FLAT (GEMM_KFLAT): K is the flat index of the packed lower-tile layout, walked in chunks of 16;
 // kcols[] then holds chunk indices.
-template <bool FLAT>
+// TB = 16x16 blocks per wave and dimension: 4 -> the 128 x 128 tile; 5 -> a 160 x 160 tile (25 accumulators = 200 VGPRs per
+// lane; two images of 160 x 16 doubles, double-buffered = 80 KB per workgroup -- two workgroups fill the CU's 160 KB of
+// LDS exactly).  The larger tile moves 0.8 of the panel bytes per flop, spends 100 instead of 64 MFMAs per wave between
+// barriers, and nvar = 4000 = 25 x 160 has no edge tiles at all.
+template <bool FLAT, int TB>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p) {
-  constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
+  constexpr int BM = 32 * TB, BN = 32 * TB, TM = TB, TN = TB;
   constexpr int LA = BM * BK;                   // doubles per image (unpadded)
-  __shared__ double lds[2 * 2 * LA];
+  extern __shared__ double lds[];               // 2 * 2 * LA doubles
   const GemmDesc& d = p.d;
-  int tm, tn;
-  {
+  int tm, tn, ks, bz;
+  if (p.n2 >= 0) {
+    // regular tiles of all splits first, short tiles last (see GemmParams): the equally long workgroups keep their
+    // lock-step through K, and the short ones fill the slots of the last round instead of a launch of their own
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int q1 = p.n1 >> 3, q2 = p.n2 >> 3;
+    int2 tt;
+    if (l < d.ksplit * q1) { ks = l / q1; tt = p.tile_list[xcd * q1 + l % q1]; }
+    else { const int l2 = l - d.ksplit * q1; ks = l2 / q2; tt = p.tile_list2[xcd * q2 + l2 % q2]; }
+    tm = tt.x;
+    tn = tt.y;
+    bz = 0;
+  } else {
     int bid = blockIdx.x, nwg = gridDim.x;
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     int2 tt = p.tile_list[swz];
     tm = tt.x;
     tn = tt.y;
+    ks = blockIdx.z % d.ksplit;
+    bz = blockIdx.z / d.ksplit;
   }
   if (tm < 0) return;      // padding entry of the tile list
-  const int ks = blockIdx.z % d.ksplit;
-  const int bz = blockIdx.z / d.ksplit;
   const double* Ag = d.A + (long)bz * d.bA;
   const double* Bg = d.B + (long)bz * d.bB;
   double* __restrict__ Cg = d.C + (long)bz * d.bC + (long)ks * d.sCs;
@@ -507,11 +527,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   const int m0 = tm * BM, n0 = tn * BN;
   // staging geometry: instruction j of wave w covers image rows 8*(w + 4j) .. +7
   const int lrow = lane >> 3, lpair = lane & 7;
-  const double* pa[4];
-  const double* pb[4];
+  const double* pa[TB];
+  const double* pb[TB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int row = 8 * (w + 4 * j) + lrow;                  // tile-local row 0..127
+  for (int j = 0; j < TB; ++j) {
+    int row = 8 * (w + 4 * j) + lrow;                  // tile-local row 0 .. BM-1
     int src_pair = lpair ^ ((row >> 1) & 7);           // swizzle on the source
     int ra = m0 + row, rb = n0 + row;
     if (ra >= d.M) ra = d.M - 1;
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
     double* sa = lds + buf * (2 * LA);
     double* sb = sa + LA;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TB; ++j) {
       const int r8 = 8 * (w + 4 * j);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kb),
                                        (__attribute__((address_space(3))) void*)(sa + r8 * BK), 16, 0, 0);
@@ -581,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
         bool need = (m0 + 16 * bm < d.M) && (n0 + 16 * bn < d.N);
         if ((diag_lo && bm < bn) || (diag_up && bn < bm)) need = false;
         if (d.flags & GEMM_NO_SKIP) need = true;
-        if (need) smask |= 1u << (i * 4 + j);
+        if (need) smask |= 1u << (i * TN + j);
       }
   }
   bool more = FLAT ? left > 0 : segc < segcend;
@@ -593,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   int cur = 0;
   // two copies of the K loop (see gemm_f64_lds_kernel): the unmasked one for tiles whose 16 blocks are all needed,
   // the masked one for edge and diagonal tiles
-  if (smask == 0xffffu) {
+  if (smask == (1u << (TM * TN)) - 1u) {
     while (more) {
       const bool have_next = FLAT ? left > 0 : segc < segcend;
       if (have_next) {
@@ -636,28 +656,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
       const double* sa = lds + cur * (2 * LA);
       const double* sb = same_panel ? sa : sa + LA;
       if (smask != 0u) {
-        double fa[BK / 4][TM], fb[BK / 4][TN];      // all fragments of the K-step first (see gemm_f64_lds_kernel)
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
+          double fa[TM], fb[TN];
           const int k = kk * 4 + fk;
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             int row = (2 * i + wm) * 16 + fr;
-            fa[kk][i] = sa[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+            fa[i] = sa[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             int row = (2 * j + wn) * 16 + fr;
-            fb[kk][j] = sb[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
+            fb[j] = sb[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)];
           }
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              if (smask & (1u << (i * 4 + j))) LRN_MFMA_INPLACE(acc[i][j], fa[kk][i], fb[kk][j]);
+              if (smask & (1u << (i * TN + j))) LRN_MFMA_INPLACE(acc[i][j], fa[i], fb[j]);
+        }
       }
       __syncthreads();
       cur ^= 1;
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if (!(smask & (1u << (i * 4 + j)))) continue;       // (GEMM_DIAG_LOWER: those slab entries are never read)
+      if (!(smask & (1u << (i * TN + j)))) continue;       // (GEMM_DIAG_LOWER: those slab entries are never read)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int m = m0 + (2 * i + wm) * 16 + MFMA_F64_ROW(lane, r);
@@ -817,7 +835,8 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit;
   bool small = (d.flags & GEMM_SMALL_TILE) ||
                (t128 < 256 && !(d.flags & (GEMM_OFFDIAG_X2 | GEMM_C_PACKED | GEMM_C_MIRROR)) && !kseg && !kfrom);
-  const int BMv = small ? 64 : 128;
+  const bool big = kflat && (d.flags & GEMM_TILE160);       // 160 x 160 tile of the K-contiguous rank-k update
+  const int BMv = small ? 64 : (big ? 160 : 128);
   p.tilesM = (d.M + BMv - 1) / BMv;
   p.tilesN = (d.N + BMv - 1) / BMv;
   if (kflat) {
@@ -867,6 +886,34 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   }
   int ntile = 0;
   if (d.tile_class != 0 && small) return gemm_fail(LRN_ERR_ARG, "gemm: tile_class needs the 128 tile");
+  p.tile_list2 = nullptr;
+  p.n1 = 0;
+  p.n2 = -1;
+  if (d.tile_class == 3) {
+    if (!kflat || d.batch != 1) return gemm_fail(LRN_ERR_ARG, "gemm: tile_class 3 is for the K-contiguous rank-k update");
+    const int trif = d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER);
+    const bool em = (d.M % BMv) != 0, en = (d.N % BMv) != 0, dg = (d.flags & (GEMM_DIAG_LOWER | GEMM_DIAG_UPPER)) != 0;
+    int c1 = 0, c2 = 0;
+    p.tile_list = get_tile_list(p.tilesM, p.tilesN, trif, &c1, 1, em, en, dg);
+    p.tile_list2 = get_tile_list(p.tilesM, p.tilesN, trif, &c2, 2, em, en, dg);
+    if (!p.tile_list || !p.tile_list2) return gemm_fail(LRN_ERR_NOMEM, "gemm: tile list allocation failed");
+    p.n1 = c1;
+    p.n2 = c2;
+    if (c1 + c2 == 0) return LRN_OK;
+    if (c1 == 0) { p.tile_list = p.tile_list2; p.n1 = c2; p.n2 = 0; }     // (only short tiles: they are the first list)
+    const long wgs = 8L * d.ksplit * ((p.n1 >> 3) + (p.n2 >> 3));
+    if (wgs > 0x7fffffffL) return gemm_fail(LRN_ERR_ARG, "gemm: grid too large");
+    dim3 grid1((unsigned)wgs, 1, 1);
+    if (big) {
+      static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 160 * BK * 8) == hipSuccess;
+      if (!attr_ok) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5>), grid1, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
+    } else {
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4>), grid1, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
   p.tile_list = get_tile_list(p.tilesM, p.tilesN, d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER), &ntile, d.tile_class,
                               d.tile_class != 0 && (d.M % BMv) != 0, d.tile_class != 0 && (d.N % BMv) != 0,
                               d.tile_class != 0 && (d.flags & (GEMM_DIAG_LOWER | GEMM_DIAG_UPPER)) != 0);
@@ -879,11 +926,18 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   if (grid.z > 65535) return gemm_fail(LRN_ERR_ARG, "gemm: grid.z > 65535");
   const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE | GEMM_C_PACKED | GEMM_C_MIRROR);
   if (kflat) {
-    hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true>), grid, dim3(256), 0, st, p);
+    if (big) {
+      static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 160 * BK * 8) == hipSuccess;
+      if (!attr_ok) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5>), grid, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
+    } else {
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4>), grid, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
+    }
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (kseg && kseg_lds_path_ok(d)) {
-    hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<false, 4>), grid, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (!small && !kseg && lds_path_ok(d)) {

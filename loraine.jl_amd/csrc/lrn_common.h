@@ -60,6 +60,7 @@ enum : int {
   GEMM_DIAG_LOWER = 8192,  // K-contiguous kernels (GEMM3 / GEMM3'): in diagonal tiles only the 16x16 blocks on and below
                            // the diagonal (m >= n) are computed and stored (the caller never reads the others)
   GEMM_DIAG_UPPER = 16384, // same for n >= m (what GEMM_DIAG_LOWER becomes when gemm() transposes the problem)
+  GEMM_TILE160 = 65536,    // GEMM_KFLAT only: 160 x 160 workgroup tile (gemm_f64_kseg_lds_kernel<true, 5>)
   GEMM_NO_SKIP = 32768,    // measurement only (option "gemm_no_skip"): compute every block of every tile
   GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower layout;
                            // the first kflat_nsd splits cover the diagonal blocks [0, kflat_diag), the
@@ -122,7 +123,8 @@ struct GemmDesc {
   long kflat_total = 0, kflat_diag = 0;
   int kflat_nsd = 0;
   int tile_class = 0;      // 0 all tiles; 1 only tiles whose blocks are all computed; 2 only the tiles with skipped blocks
-                           // (edge tiles, GEMM_DIAG_* diagonal tiles) -- see get_tile_list
+                           // (edge tiles, GEMM_DIAG_* diagonal tiles) -- see get_tile_list; 3 (GEMM_KFLAT): both in one
+                           // launch, class 1 of every split first, class 2 last
   int kstagger = 0;        // GEMM_KFLAT: workgroup (tm, tn) starts its K walk ((tm + tn) & 7) * kstagger chunks into
                            // its split and wraps around (see gemm_f64_kseg_lds_kernel)
 };

@@ -533,14 +533,22 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   }
   {
     const int M = nd, N = nd;
+    // workgroup tile of GEMM3': 128 x 128, or 160 x 160 (gemm_f64_kseg_lds_kernel<true, 5>: 0.8 of the panel bytes per
+    // flop, 100 MFMAs per wave between barriers) where its grid covers the lower triangle with > 5 % less area -- at
+    // C4 (4000 = 25 x 160 = 31.25 x 128) both run within 2 % of each other, 128 ahead on most boxes: the kernel is bound
+    // by the MFMA pipe at the clock it is left, not by its panel traffic (option "gemm3_tile": 0 auto, 128, 160)
+    auto tri_area = [&](long ts) { const long tt = (nd + ts - 1) / ts; return tt * (tt + 1) / 2 * ts * ts; };
+    const bool t160 = c->opt.gemm3_tile == 160 ||
+                      (c->opt.gemm3_tile == 0 && nd >= 320 && (double)tri_area(160) < 0.95 * (double)tri_area(128));
+    const int TS3 = t160 ? 160 : TS;
     long tiles = 0;
-    const int tM = (M + TS - 1) / TS;
+    const int tM = (M + TS3 - 1) / TS3;
     for (int tn = 0; tn < tM; ++tn) tiles += tM - tn;
     // GEMM3' runs as two launches: the regular tiles -- all equally long, lock-step through K -- and then the tiles
     // with blocks to skip (diagonal tiles: blocks above the diagonal; the last tile row when nd % 128 != 0).  The
     // split-K factor is chosen for the regular launch (the bulk of the work).
     const bool two_launches = !c->opt.gemm_no_skip && tM > 2;
-    if (two_launches) tiles -= tM + ((M % TS) ? tM - 1 : 0);
+    if (two_launches) tiles -= tM + ((M % TS3) ? tM - 1 : 0);
     // chunk ranges of the runs and the split-K budget (see below) divided over them by length
     struct RunK { long d0, d1, o0, o1; int ks, nsd; };
     std::vector<RunK> rk;
@@ -615,23 +623,24 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g3.kflat_cstride = cstride;
       g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
       g3.M = M; g3.N = N;
-      g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT | GEMM_DIAG_LOWER | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
+      g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT | GEMM_DIAG_LOWER | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
+                 (t160 ? GEMM_TILE160 : 0);
       g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = 1;
       g3.kflat_kb = kb.data(); g3.kflat_ke = ke.data();
       g3.kstagger = c->opt.gemm3_stagger;
       g3.ksplit = nslab; g3.sCs = (long)M * N;
-      if (two_launches) {
+      // regular tiles of every split first, the tiles with skipped blocks last, in one launch (tile_class 3)
+      if (two_launches && c->opt.gemm3_sched == 0) {         // measurement: the two classes as two launches
         g3.tile_class = 1;
         LRN_TRY(gemm(c->stream, g3));
         toc(c, "gemm3");
         tic(c);
         g3.tile_class = 2;
-        LRN_TRY(gemm(c->stream, g3));
-        toc(c, "gemm3");                // (two launches of one kernel: lrn_get_count("gemm3") = 2 per assembly)
       } else {
-        LRN_TRY(gemm(c->stream, g3));
-        toc(c, "gemm3");
+        g3.tile_class = two_launches ? 3 : 0;
       }
+      LRN_TRY(gemm(c->stream, g3));
+      toc(c, "gemm3");
     }
     tic(c);
     hipLaunchKernelGGL(reduce_slabs_w_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,

@@ -550,3 +550,29 @@ def test_reference_timer_names_are_aliases(dev):
     assert dev.timing("BBBBone3") == pytest.approx(dev.timing("gemm3") + dev.timing("reduce3"))
     assert dev.timing("BBBBone4") == 0.0
     assert dev.timing("BBBBs") == dev.timing("assemble") >= dev.timing("BBBBone")
+
+
+@pytest.mark.parametrize("nvar", [320, 960, 1000])
+def test_gemm3_tile_and_schedule_variants_agree(dev, nvar):
+    """GEMM3' with the 128 and the 160 workgroup tile, as one launch (regular tiles of every split first, short tiles
+    last) and as two.  The schedule does not touch the arithmetic (bit-identical); the tile size changes the tile
+    count and with it the split-K factor, i.e. how the K range is cut into slabs (1e-14)."""
+    msz = 200
+    dev.synthetic_dense_model(msz, nvar, 41)
+    W, G = _spd(msz, 42)
+    dev.set_scaling(0, W, G)
+    dev.set_option("schur_chol", 1)
+    Hs = []
+    try:
+        for tile, sched in ((128, 1), (160, 1), (128, 0), (160, 0)):
+            dev.set_option("gemm3_tile", tile)
+            dev.set_option("gemm3_sched", sched)
+            Hs.append(np.tril(dev.schur_assemble(0, want_H=True)))
+    finally:
+        dev.set_option("gemm3_tile", 0)
+        dev.set_option("gemm3_sched", 1)
+        dev.set_option("schur_chol", -1)
+    assert np.array_equal(Hs[2], Hs[0]) and np.array_equal(Hs[3], Hs[1])
+    assert relerr(Hs[1], Hs[0]) < 1e-14
+    A = np.stack([dev.get_constraint(0, k) for k in range(8)])
+    assert relerr(Hs[0][:8, :8], np.tril(_brute_H(A, W))) < 1e-13
