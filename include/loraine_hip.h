@@ -60,19 +60,21 @@ int lrn_synthetic_dense_model(lrn_ctx* ctx, int msz, int nvar, uint64_t seed);
 int lrn_synthetic_dense_problem(lrn_ctx* ctx, uint64_t seed, double* b_out, double* y0_out, double* normC);
 /* dense copy of constraint matrix A_k (0-based k) of block ilmi, msz x msz */
 int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
-/* tuning knobs (process-wide): "dense_threshold" (nnz above which a branch-1 constraint takes
+/* tuning knobs (per context): "dense_threshold" (nnz above which a branch-1 constraint takes
  * the MFMA path), "profile" (0/1), "t_batch", "p_batch", "shard_bs" (0 = auto), "jacobi_warm" (0/1), "jacobi_block",
  * "jacobi_inner", "jacobi_wgs", "pivot_boost" (relative pivot level boosted in lrn_schur_factor, 0 = off),
  * "prec_eig" (0 auto / 1 full Jacobi eigendecomposition / 2 Lanczos extremes in lrn_prec_setup),
  * "matvec_sparse" (0 auto / 1 dense GEMM mat-vec / 2 pattern-restricted mat-vec when every
- * constraint is sparse), "svd_sdc" (0/1,
- * experimental divide-and-conquer start of the SVD for msz >= "sdc_min"; "sdc_leaf", "sdc_l0"),
+ * constraint is sparse),
  * "schur_chol" (dense Schur assembly through the Cholesky factor of W: -1 auto -- H_ij = <L'A_iL, L'A_jL> when
  * every constraint of the block is dense, T_k = L (L'A_kL) L' otherwise, both for msz >= 256 --,
  * 0 never (T_k = W A_k W), 1 as auto without the size threshold, 2 the T_k form only),
- * "gemm3_ksplit" (split-K factor of the inner-product GEMM, 0 = auto), "gemm3_stagger" (experiment: K-walk stagger of
- * the workgroups of GEMM3' in chunks of 16, 0 = off),
- * "reset_timing". */
+ * "schur_plan" (-1 decide locally / 0 / 1: the assembly path every rank of a sharded run agreed on, see lrn_schur_plan),
+ * "gemm3_ksplit" (split-K factor of the inner-product GEMM, 0 = auto), "gemm3_sched" (1: regular and masked tiles of
+ * GEMM3' in one launch, 0: two launches), "gemm3_tile" (0 auto / 128 / 160), "gemm_no_skip" (1: no block masks in the
+ * three GEMMs of the factor path -- A/B switch), "gemm3_stagger" (experiment: K-walk stagger of the workgroups of
+ * GEMM3' in chunks of 16, 0 = off), "pair_lanes" (lanes per entry of the sparse pair kernel: 0 auto / 4 / 8 / 16 / 64),
+ * "jacobi_cross" (1: cross-pair rotations only after round 0), "reset_timing". */
 int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
 /* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */
 int lrn_set_shard(lrn_ctx* ctx, int rank, int world);
@@ -178,11 +180,6 @@ int lrn_dbg_eigmin(lrn_ctx* ctx, int n, const double* M, double* lam, int* steps
 /* k largest eigenpairs (ascending; U_top n x k column-major, may be NULL), smallest eigenvalue and
  * trace of a symmetric matrix: what the preconditioner setup consumes of `eigen(W)`
  * (src/Solvers.jl:642-650,706-722); unit test of the Lanczos path (option "prec_eig") */
-/* approximate eigenvectors V (orthogonal, V'KV nearly diagonal) of a symmetric positive definite K by
- * spectral divide and conquer (QDWH sign function + CholeskyQR2; the large-msz starting basis of
- * lrn_prepare_w when option "svd_sdc" is on); lrn_get_count keys sdc_splits, sdc_leaves, sdc_qdwh_its,
- * sdc_fallbacks */
-int lrn_dbg_sdc(lrn_ctx* ctx, int n, const double* K, double* V);
 int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top, double* U_top,
                     double* lam_min, double* trace, int* steps);
 

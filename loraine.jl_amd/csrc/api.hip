@@ -56,7 +56,6 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->lzbuf);
   release(c->lxbuf);
   release(c->ezbuf);
-  release(c->sdcbuf);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -87,10 +86,6 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "gemm3_sched")) c->opt.gemm3_sched = (int)value;
   else if (!strcmp(key, "gemm3_tile")) c->opt.gemm3_tile = (int)value;
   else if (!strcmp(key, "gemm3_stagger")) c->opt.gemm3_stagger = (int)value;
-  else if (!strcmp(key, "svd_sdc")) c->opt.svd_sdc = (int)value;
-  else if (!strcmp(key, "sdc_min")) c->opt.sdc_min = (int)value;
-  else if (!strcmp(key, "sdc_leaf")) c->opt.sdc_leaf = (int)value;
-  else if (!strcmp(key, "sdc_l0")) c->opt.sdc_l0 = value;
   else if (!strcmp(key, "jacobi_wgs")) c->opt.jacobi_wgs = (int)value;
   else if (!strcmp(key, "jacobi_block")) c->opt.jacobi_block = (int)value;
   else if (!strcmp(key, "jacobi_inner")) c->opt.jacobi_inner = (int)value;

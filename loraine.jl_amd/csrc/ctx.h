@@ -72,8 +72,6 @@ struct LrnOptions {
   int gemm3_sched = 1;            // 1: one launch, regular tiles of every split first, short tiles last; 0: two launches
   int gemm3_tile = 0;             // workgroup tile of GEMM3': 0 auto, 128, 160
   int gemm3_stagger = 0;          // K-walk stagger of GEMM3' in chunks of 16 (GemmDesc::kstagger)
-  int svd_sdc = 0, sdc_min = 4000, sdc_leaf = 768;
-  double sdc_l0 = 1e-6;
   int jacobi_inner = 0;           // sweeps over the pair's Gram matrix per round (more did not cut the outer sweeps: 1)
   int jacobi_wgs = 0;             // workgroups per Gram / apply launch the row chunking aims for: 0 auto
   int jacobi_block = 0;           // column block width: 0 auto (32 for n >= 5000), 16, 32
@@ -127,7 +125,7 @@ struct lrn_ctx {
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // generic scratch
-  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lxbuf, ezbuf, sdcbuf;
+  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lxbuf, ezbuf;
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
 };

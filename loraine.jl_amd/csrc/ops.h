@@ -10,6 +10,4 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info);                    // N
 // k largest eigenpairs (ascending), smallest eigenvalue and trace of a dense symmetric matrix
 int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
                      double* trace, int* steps_out);
-// approximate eigenvectors of a symmetric positive definite matrix by spectral divide and conquer (sdc.hip)
-int sdc_eig(lrn_ctx* c, double* K, int n, double* V);
 }  // namespace lrn

@@ -130,24 +130,7 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   // SVD of CC = LS' LX = U D V' by one-sided Jacobi on CC' = LX' LS: its columns are rotated by
   // U and converge to V D, so V = (columns / D) needs no accumulation of rotations -- the rounds
   // are bandwidth-bound (every round streams the whole matrix), this removes the V half of it.
-  const bool use_sdc = c->opt.svd_sdc != 0 && n >= c->opt.sdc_min;
   int sweeps = 0;
-  if (use_sdc) {
-    // large msz: starting basis V0 from the spectral divide and conquer on K = CC' CC = L_X' S L_X
-    // (sdc.hip), then one-sided Jacobi on CC V0 accumulating into V0 until ITS test passes -- the
-    // accuracy of (D, V) is Jacobi's; the GEMM-rich part only removes the 10+ sweeps of the linear phase
-    tic(c);
-    LRN_TRY(gemm_nn(st, n, LS, true, LX, false, CC));                          // CC = LS' LX
-    LRN_TRY(gemm_nn(st, n, CC, true, CC, false, Y, GEMM_TRI_LOWER));           // K = CC' CC
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, Y, n);
-    toc(c, "prepw_gemm");
-    tic(c);
-    LRN_TRY(sdc_eig(c, Y, n, V));
-    LRN_TRY(gemm_nn(st, n, CC, false, V, false, Y));                           // CC V0
-    LRN_TRY(jacobi_svd(c, Y, V, b.D.as<double>(), n, &sweeps, true));
-    c->counts["svd_sweeps"] = sweeps;
-    toc(c, "prepw_svd");
-  } else {
   tic(c);
   LRN_TRY(gemm_nn(st, n, LX, true, LS, false, CC));
   // warm start: the left singular vectors of the previous IP iterate nearly orthogonalise the
@@ -163,12 +146,11 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, CC, b.D.as<double>(), n, 2, V);
   c->counts["svd_sweeps"] = sweeps;
   toc(c, "prepw_svd");
-  }
   tic(c);
   // G = LX (V D^-1/2)
   hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 0, CC);
   LRN_TRY(gemm_nn(st, n, LX, false, CC, false, b.G.as<double>()));
-  if (c->opt.jacobi_warm && !use_sdc) {          // U = LS' G D^-1/2  (G = LS^-T U D^1/2) for the next warm start
+  if (c->opt.jacobi_warm) {          // U = LS' G D^-1/2  (G = LS^-T U D^1/2) for the next warm start
     LRN_TRY(ensure(c, b.Vprev, mm));
     LRN_TRY(gemm_nn(st, n, LS, true, b.G.as<double>(), false, CC));
     hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, CC, b.D.as<double>(), n, 0,

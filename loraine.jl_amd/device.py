@@ -356,12 +356,6 @@ class Device:
         self._chk(self.lib.lrn_ip_stats(self.h, ptr(out)), "lrn_ip_stats")
         return out[:5 * nl].reshape(nl, 5)
 
-    def dbg_sdc(self, K):
-        K = f64(K)
-        V = np.zeros(K.shape, order="F")
-        self._chk(self.lib.lrn_dbg_sdc(self.h, K.shape[0], ptr(K), ptr(V)), "lrn_dbg_sdc")
-        return V
-
     def dbg_lanczos(self, M, k, vectors=True):
         M = f64(M)
         n = M.shape[0]

@@ -329,51 +329,6 @@ def test_halpha_apply_with_linear_rows(dev, name, erank):
     assert relerr(xg, xr) < 1e-6
 
 
-@pytest.mark.parametrize("n,leaf", [(300, 96), (700, 200)])
-def test_spectral_divide_and_conquer_basis(dev, n, leaf):
-    """sdc.hip (experimental large-msz start for prepare_W, option svd_sdc): QDWH sign function +
-    CholeskyQR2 splits; the basis must be orthogonal and nearly diagonalise K."""
-    rng = np.random.default_rng(n)
-    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
-    lam = np.exp(rng.uniform(np.log(1.0), np.log(50.0), n))
-    K = (Q * lam) @ Q.T
-    K = 0.5 * (K + K.T)
-    dev.set_option("sdc_leaf", leaf)
-    try:
-        V = dev.dbg_sdc(K)
-    finally:
-        dev.set_option("sdc_leaf", 768)
-    assert dev.count("sdc_splits") >= 2 and dev.count("sdc_fallbacks") == 0
-    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-11
-    G = V.T @ K @ V
-    assert np.linalg.norm(G - np.diag(np.diag(G))) < 1e-6 * np.linalg.norm(np.diag(G))
-
-
-def test_prepare_w_with_sdc_start(dev):
-    """prepare_W with the divide-and-conquer starting basis forced at a small size: same W as the
-    Jacobi-only path (the final Jacobi sweeps decide the accuracy either way)."""
-    m = 400
-    X = _spd(m, 1, 1e3)
-    S = _spd(m, 2, 1e3)
-    import scipy.sparse as sp
-    A = [[sp.csc_matrix((m, m)), sp.identity(m, format="csc")]]
-    om = lo.make_model(A, np.ones(1), 0.0, None, None)
-    dev.upload_model(om.AA, om.sigmaA, om.qA, om.msizes)
-    info, base = dev.prepare_w(0, X, S)
-    assert info == 0
-    for k, v in (("svd_sdc", 1), ("sdc_min", 100), ("sdc_leaf", 128)):
-        dev.set_option(k, v)
-    try:
-        info, out = dev.prepare_w(0, X, S)
-    finally:
-        for k, v in (("svd_sdc", 0), ("sdc_min", 4000), ("sdc_leaf", 768)):
-            dev.set_option(k, v)
-    assert info == 0 and dev.count("sdc_splits") >= 1
-    assert relerr(out["W"], base["W"]) < 1e-10
-    assert relerr(out["W"] @ S @ out["W"], X) < 1e-9
-    assert np.allclose(np.sort(out["D"]), np.sort(base["D"]), rtol=1e-10)
-
-
 def test_partial_matvec_two_blocks_with_linear_rows(dev):
     """kit=1 multi-GPU operator on vib3 (two LMI blocks, 72 linear rows): the partial mat-vecs of a 4-way
     sharding add up to MyA(x); the C_lin term is contributed by rank 0 only."""
