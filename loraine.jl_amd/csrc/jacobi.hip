@@ -235,13 +235,13 @@ __device__ __forceinline__ bool jrot(double al, double be, double ga, double tol
 // for the full schedule in round 0 of every sweep, where each block occurs once -- so a sweep still visits every
 // column pair once, at about half the dependent steps (the latency of this kernel is the round's time at msz ~ 1000).
 __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict__ Gpart, int nchunk, int n, int nbk2,
-                                                        int round, double tol, int inner, int full,
+                                                        int round, double tol, double big2, int inner, int full,
                                                         double* __restrict__ Rbuf,
                                                         int* __restrict__ flags, int* __restrict__ nrot) {
   __shared__ double G[2][32][33];
   __shared__ double R[32][33];
   __shared__ unsigned char sched[31][16][2];   // round-robin schedule of the 32 local columns
-  __shared__ int anyrot;
+  __shared__ int anyrot, anybig;
   int I, J;
   rr_pair(nbk2, round, blockIdx.x, &I, &J);
   const int t = threadIdx.x;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict
     if (t == 0) flags[blockIdx.x] = 0;
     return;
   }
-  if (t == 0) anyrot = 0;
+  if (t == 0) { anyrot = 0; anybig = 0; }
   const int nsteps = full ? 31 : 16;
   for (int e = t; e < nsteps * 16; e += 256) {
     int p, q;
@@ -275,47 +275,72 @@ __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict
   __syncthreads();
   const int k1 = t >> 4, k2 = t & 15;
   int cur = 0;
-  bool rotated = false;
+  bool rotated = false, big = false;
+  // R <- R J of a step is applied one step late: its LDS round trip then runs under the next step's rotation
+  // parameters (one wave per SIMD: every latency of the chain is exposed) -- (pc, ps, pp, pq) is the pending rotation
+  double pc = 1.0, ps = 0.0;
+  int pp = 0, pq = 0;
+  const int src = (threadIdx.x & 0x30) | k1;
   // inner > 1: further sweeps on the same Gram matrix (cheap next to streaming the panels at large n)
   for (int istep = 0; istep < nsteps * inner; ++istep) {
     const int step = istep % nsteps;
-    const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
-    const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
+    int p1, q1, p2, q2;
+    if (full) {
+      p1 = sched[step][k1][0]; q1 = sched[step][k1][1];
+      p2 = sched[step][k2][0]; q2 = sched[step][k2][1];
+    } else {
+      p1 = k1; q1 = 16 + ((k1 + step) & 15);
+      p2 = k2; q2 = 16 + ((k2 + step) & 15);
+    }
+    // every LDS read of the step is issued before the dependent FP64 chain of the rotation parameters
+    const double al = G[cur][p2][p2], be = G[cur][q2][q2], ga = G[cur][p2][q2];
+    const double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
+    double rx[2], ry[2];
+    if (istep > 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { rx[h] = R[k1 + 16 * h][pp]; ry[h] = R[k1 + 16 * h][pq]; }
+    }
     // one rotation per thread (pair k2); the row pair's (k1) comes from the lane of this wave whose
     // k2 equals my k1 -- halves the dependent FP64 chain of a step
     double c1, s1, c2, s2;
-    rotated |= jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
-    {
-      const int src = (threadIdx.x & 0x30) | k1;
-      c1 = __shfl(c2, src, 64);
-      s1 = __shfl(s2, src, 64);
-    }
+    rotated |= jrot(al, be, ga, tol, &c2, &s2);
+    big |= ga * ga > big2 * al * be;
+    c1 = __shfl(c2, src, 64);
+    s1 = __shfl(s2, src, 64);
     // 2x2 block (pair k1 rows, pair k2 columns):  B' = J1' B J2
-    double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
     double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
     double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
     G[cur ^ 1][p1][p2] = c1 * t00 - s1 * t10;
     G[cur ^ 1][p1][q2] = c1 * t01 - s1 * t11;
     G[cur ^ 1][q1][p2] = s1 * t00 + c1 * t10;
     G[cur ^ 1][q1][q2] = s1 * t01 + c1 * t11;
-    // R <- R J: rows k1 and k1+16, column pair k2 (each element owned by one thread)
+    // R <- R J of the PREVIOUS step: rows k1 and k1+16, its column pair k2 (each element owned by one thread)
+    if (istep > 0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int i = k1 + 16 * h;
-      double x = R[i][p2], y = R[i][q2];
-      R[i][p2] = c2 * x - s2 * y;
-      R[i][q2] = s2 * x + c2 * y;
+      for (int h = 0; h < 2; ++h) {
+        R[k1 + 16 * h][pp] = pc * rx[h] - ps * ry[h];
+        R[k1 + 16 * h][pq] = ps * rx[h] + pc * ry[h];
+      }
     }
+    pc = c2; ps = s2; pp = p2; pq = q2;
     __syncthreads();
     cur ^= 1;
   }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {           // the last step's rotation
+    double x = R[k1 + 16 * h][pp], y = R[k1 + 16 * h][pq];
+    R[k1 + 16 * h][pp] = pc * x - ps * y;
+    R[k1 + 16 * h][pq] = ps * x + pc * y;
+  }
   if (rotated) anyrot = 1;
+  if (big) anybig = 1;
   __syncthreads();
   double* ro = Rbuf + (long)blockIdx.x * 1024;
   for (int e = t; e < 1024; e += 256) ro[e] = R[e >> 5][e & 31];
   if (t == 0) {
     flags[blockIdx.x] = anyrot;
     if (anyrot) atomicAdd(nrot, 1);
+    if (anybig) atomicAdd(nrot + 1, 1);           // a rotation above the early-stop level (jacobi_svd)
   }
 }
 
@@ -457,13 +482,14 @@ __global__ __launch_bounds__(256) void jb2_gram_kernel(const double* __restrict_
 // One (or `inner`) cyclic sweep(s) over the 64 x 64 Gram matrix: 63 steps of 32 disjoint rotations,
 // one thread per 2x2 block (pair k1 x pair k2), double-buffered, one barrier per step.
 __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restrict__ Gpart, int nchunk, int n, int nbk2,
-                                                          int round, double tol, int inner, double* __restrict__ Rbuf,
+                                                          int round, double tol, double big2, int inner,
+                                                          double* __restrict__ Rbuf,
                                                           int* __restrict__ flags, int* __restrict__ nrot) {
   extern __shared__ double jb2_sh[];
   double (*G)[64][65] = reinterpret_cast<double (*)[64][65]>(jb2_sh);                 // [2][64][65]
   double (*R)[65] = reinterpret_cast<double (*)[65]>(jb2_sh + 2 * 64 * 65);           // [64][65]
   unsigned char (*sched)[32][2] = reinterpret_cast<unsigned char (*)[32][2]>(jb2_sh + 3 * 64 * 65);   // [63][32][2]
-  __shared__ int anyrot;
+  __shared__ int anyrot, anybig;
   int I, J;
   rr_pair(nbk2, round, blockIdx.x, &I, &J);
   const int t = threadIdx.x;
@@ -471,7 +497,7 @@ __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restri
     if (t == 0) flags[blockIdx.x] = 0;
     return;
   }
-  if (t == 0) anyrot = 0;
+  if (t == 0) { anyrot = 0; anybig = 0; }
   for (int e = t; e < 63 * 32; e += 1024) {
     int p, q;
     rr_pair(64, e >> 5, e & 31, &p, &q);
@@ -491,42 +517,58 @@ __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restri
   __syncthreads();
   const int k1 = t >> 5, k2 = t & 31;
   int cur = 0;
-  bool rotated = false;
+  bool rotated = false, big = false;
+  double pc = 1.0, ps = 0.0;                          // R <- R J one step late, as in jb_rotate_kernel
+  int pp = 0, pq = 0;
+  const int src = (threadIdx.x & 0x20) | k1;          // lane of this wave with k2 == my k1
   for (int istep = 0; istep < 63 * inner; ++istep) {
     const int step = istep % 63;
     const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
     const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
-    double c1, s1, c2, s2;
-    rotated |= jrot(G[cur][p2][p2], G[cur][q2][q2], G[cur][p2][q2], tol, &c2, &s2);
-    {
-      const int src = (threadIdx.x & 0x20) | k1;      // lane of this wave with k2 == my k1
-      c1 = __shfl(c2, src, 64);
-      s1 = __shfl(s2, src, 64);
+    const double al = G[cur][p2][p2], be = G[cur][q2][q2], ga = G[cur][p2][q2];
+    const double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
+    double rx[2], ry[2];
+    if (istep > 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { rx[h] = R[k1 + 32 * h][pp]; ry[h] = R[k1 + 32 * h][pq]; }
     }
-    double b00 = G[cur][p1][p2], b01 = G[cur][p1][q2], b10 = G[cur][q1][p2], b11 = G[cur][q1][q2];
+    double c1, s1, c2, s2;
+    rotated |= jrot(al, be, ga, tol, &c2, &s2);
+    big |= ga * ga > big2 * al * be;
+    c1 = __shfl(c2, src, 64);
+    s1 = __shfl(s2, src, 64);
     double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
     double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
     G[cur ^ 1][p1][p2] = c1 * t00 - s1 * t10;
     G[cur ^ 1][p1][q2] = c1 * t01 - s1 * t11;
     G[cur ^ 1][q1][p2] = s1 * t00 + c1 * t10;
     G[cur ^ 1][q1][q2] = s1 * t01 + c1 * t11;
+    if (istep > 0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int i = k1 + 32 * h;
-      double x = R[i][p2], y = R[i][q2];
-      R[i][p2] = c2 * x - s2 * y;
-      R[i][q2] = s2 * x + c2 * y;
+      for (int h = 0; h < 2; ++h) {
+        R[k1 + 32 * h][pp] = pc * rx[h] - ps * ry[h];
+        R[k1 + 32 * h][pq] = ps * rx[h] + pc * ry[h];
+      }
     }
+    pc = c2; ps = s2; pp = p2; pq = q2;
     __syncthreads();
     cur ^= 1;
   }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    double x = R[k1 + 32 * h][pp], y = R[k1 + 32 * h][pq];
+    R[k1 + 32 * h][pp] = pc * x - ps * y;
+    R[k1 + 32 * h][pq] = ps * x + pc * y;
+  }
   if (rotated) anyrot = 1;
+  if (big) anybig = 1;
   __syncthreads();
   double* ro = Rbuf + (long)blockIdx.x * 4096;
   for (int e = t; e < 4096; e += 1024) ro[e] = R[e >> 6][e & 63];
   if (t == 0) {
     flags[blockIdx.x] = anyrot;
     if (anyrot) atomicAdd(nrot, 1);
+    if (anybig) atomicAdd(nrot + 1, 1);
   }
 }
 
@@ -588,6 +630,9 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
 int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* sweeps_out, bool v_init) {
   hipStream_t st = c->stream;
   const double tol = 2.220446049250313e-16 * sqrt((double)(n > 4 ? n : 4));
+  // early stop (option "jacobi_early", default 3e-8; 0 = always run the confirming sweep): see the sweep loop
+  const double early = c->opt.jacobi_early;
+  const double big2 = early > 0.0 ? early * early : 0.0;
   const int max_sweeps = 40;
   int sweeps = 0;
   LRN_TRY(ensure(c, c->info_dev, 64));
@@ -622,28 +667,33 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
     if (wide)
       LRN_HIP(c, hipFuncSetAttribute((const void*)jb2_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2));
     for (; sweeps < max_sweeps;) {
-      LRN_HIP(c, hipMemsetAsync(cnt, 0, 4, st));
+      LRN_HIP(c, hipMemsetAsync(cnt, 0, 8, st));
       for (int round = 0; round < nbk2 - 1; ++round) {
         if (wide) {
           hipLaunchKernelGGL(jb2_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
           hipLaunchKernelGGL(jb2_rotate_kernel, dim3(npair), dim3(1024), sh2, st, Gpart, nchunk, n, nbk2, round, tol,
-                             inner, Rbuf, flags, cnt);
+                             big2, inner, Rbuf, flags, cnt);
           hipLaunchKernelGGL(jb2_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
                              Rbuf, flags);
         } else {
           hipLaunchKernelGGL(jb_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
           hipLaunchKernelGGL(jb_rotate_kernel, dim3(npair), dim3(256), 0, st, Gpart, nchunk, n, nbk2, round, tol,
-                             inner, (round == 0 || c->opt.jacobi_cross == 0) ? 1 : 0, Rbuf, flags, cnt);
+                             big2, inner, (round == 0 || c->opt.jacobi_cross == 0) ? 1 : 0, Rbuf, flags, cnt);
           hipLaunchKernelGGL(jb_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
                              Rbuf, flags);
         }
       }
-      int h = 0;
-      LRN_HIP(c, hipMemcpyAsync(&h, cnt, 4, hipMemcpyDeviceToHost, st));
+      int h[2] = {0, 0};
+      LRN_HIP(c, hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, st));
       LRN_HIP(c, hipStreamSynchronize(st));
       ++sweeps;
-      if (trace) fprintf(stderr, "[jacobi n=%d jb=%d] sweep %d: %d of %d block pairs rotated\n", n, jb, sweeps, h, npair * (nbk2 - 1));
-      if (h == 0) break;
+      if (trace)
+        fprintf(stderr, "[jacobi n=%d jb=%d] sweep %d: %d of %d block pairs rotated, %d above the early-stop level\n", n, jb,
+                sweeps, h[0], npair * (nbk2 - 1), h[1]);
+      // no rotation at all, or none whose columns were further from orthogonal than `early`: what such a sweep leaves
+      // is of second order in it (quadratic convergence of the cyclic sweep) -- below tol, so the sweep that would only
+      // confirm it is not run
+      if (h[0] == 0 || h[1] == 0) break;
     }
   }
   hipLaunchKernelGGL(colnorm_kernel, dim3(n), dim3(256), 0, st, A, n, sigma);

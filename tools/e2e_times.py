@@ -21,7 +21,7 @@ for name, opts, dr in cases:
     if only and name not in only:
         continue
     path = os.path.join(G, name + ".dat-s")
-    o = Optimizer(resident="--host" not in sys.argv); o.set_silent(True)
+    o = Optimizer(resident="--host" not in sys.argv, device=_dev); o.set_silent(True)   # options are per context
     for k, v in opts.items():
         o.set_attribute(k, v)
     o.read_from_file(path)
@@ -33,7 +33,7 @@ for name, opts, dr in cases:
     rec = dict(iters=its, obj=o.objective_value(), status=o.termination_status(), wall_s=tg,
                ms_per_iter_total=host_it, gpu_ms=g, cg_tot=o.solver.cg_iter_tot,
                svd_sweeps=[x["svd_sweeps"] for x in tr])
-    if "--cpu" in sys.argv or name in ("theta1", "maxG11"):
+    if "--cpu" in sys.argv or (name in ("theta1", "maxG11") and "--nocpu" not in sys.argv):
         t = time.perf_counter()
         s = lo.MySolver(lo.model_from_sdpa(path, datarank=dr), dict(opts, verb=0)); lo.solve(s)
         rec["cpu_wall_s"] = time.perf_counter() - t
@@ -42,4 +42,4 @@ for name, opts, dr in cases:
         rec["cpu_ms_prepw"] = float(np.mean([x["t_prepw"] for x in s.trace[1:]])) * 1e3
     print(name, json.dumps(rec), flush=True)
     out[name] = rec
-json.dump(out, open("gpurun_out/e2e_times.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("E2E_OUT", "gpurun_out/e2e_times.json"), "w"), indent=1)
