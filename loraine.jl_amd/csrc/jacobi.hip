@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void jb_gram_kernel(const double* __restrict__
 // Plane-rotation parameters that annihilate the (p,q) Gram entry (Hestenes / same formula as the
 // scalar kernel); returns false when the pair is already orthogonal to tolerance.
 // The rotation parameters sit on the critical path of every step of the Gram sweep (31 or 63 dependent
-// steps per round): v_rsq_f64 / v_rcp_f64 seeds with two Newton steps (full double accuracy for the
+// steps per round): v_rsq_f64 seeds with two Newton steps (full double accuracy for the
 // normal-range arguments that occur here) instead of the IEEE sqrt / divide expansions.
 __device__ __forceinline__ double fast_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -204,25 +204,21 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   y = y * (1.5 - hx * y * y);
   return y;
 }
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * (2.0 - x * y);
-  y = y * (2.0 - x * y);
-  return y;
-}
 
 __device__ __forceinline__ bool jrot(double al, double be, double ga, double tol, double* c, double* s) {
   *c = 1.0; *s = 0.0;
   if (!(ga * ga > tol * tol * al * be)) return false;      // |ga| > tol sqrt(al be), also rejects NaN
   // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), written as
   //   t = 2 ga / (d + sign(d) sqrt(d^2 + 4 ga^2)),  d = be - al
+  //   c^2 = (1 + |d| / r) / 2,  s = sign(d) ga / (r c),  r = sqrt(d^2 + 4 ga^2)  -- the same (small-angle) rotation
+  // with two reciprocal square roots on the dependent chain and no reciprocal
   double d = be - al, g2 = 2.0 * ga;
   double r2 = d * d + g2 * g2;
-  double h = r2 * fast_rsqrt(r2);
-  double tt = g2 * fast_rcp(d >= 0.0 ? d + h : d - h);
-  double cc = fast_rsqrt(1.0 + tt * tt);
-  *c = cc;
-  *s = cc * tt;
+  double ir = fast_rsqrt(r2);
+  double c2 = 0.5 + 0.5 * fabs(d) * ir;
+  double ic = fast_rsqrt(c2);
+  *c = c2 * ic;
+  *s = (d >= 0.0 ? ga : -ga) * ir * ic;
   return true;
 }
 
