@@ -380,7 +380,7 @@ def main():
                 alg_flops_launch = (nvar * (nvar + 1.0) / 2.0) * msz * (msz + 1.0) * dev.timing("gemm3_share") / launches_per_step
             kname = ("gemm_f64_kseg_lds_kernel<true> GEMM3' H[j,i] = <L'A_jL, L'A_iL> (packed lower tiles, split-K)"
                      if chol_path else "gemm_f64_kseg_lds_kernel<false> GEMM3 H[j,i] = <A_j, W A_i W> (lower tiles, split-K)")
-            kpat = "gemm_f64_kseg_lds_kernel<true>" if chol_path else "gemm_f64_kseg_lds_kernel<false>"
+            kpat = "gemm_f64_kseg_lds_kernel<true" if chol_path else "gemm_f64_kseg_lds_kernel<false"     # (<FLAT, tile blocks>)
         elif dom == "gemm1":
             units_per_launch = (nvar if chol_path else nown) / launches_per_step      # constraint matrices per launch
             alg_flops_launch = (2.0 / 3.0 if chol_path else (1.0 if via_l else 2.0)) * msz ** 3 * units_per_launch

@@ -23,8 +23,8 @@ python3 tools/pmc_summary_r02.py $O > $O/pmc_derived.txt 2>&1; cat $O/pmc_derive
 echo "== per-rank replay, both layouts"
 step 400 python3 tools/shard_balance.py > $O/shard_balance.txt 2>&1; grep "^\[" $O/shard_balance.txt
 echo "== parity configs end to end"
-step 600 python3 tools/e2e_times.py --cpu theta1 maxG11 > $O/e2e_a.log 2>&1
-step 400 python3 tools/e2e_times.py thetaG11 tru9 vib9 > $O/e2e_b.log 2>&1; grep -h "^[a-zA-Z0-9]* {" $O/e2e_a.log $O/e2e_b.log | cut -c1-400
+E2E_OUT=$O/e2e_a.json step 600 python3 tools/e2e_times.py --cpu theta1 maxG11 > $O/e2e_a.log 2>&1
+E2E_OUT=$O/e2e_b.json step 400 python3 tools/e2e_times.py thetaG11 tru9 vib9 > $O/e2e_b.log 2>&1; grep -h "^[a-zA-Z0-9]* {" $O/e2e_a.log $O/e2e_b.log | cut -c1-400
 echo "== full C4 solve"
 step 300 python3 tools/c4_full_solve.py > $O/c4_full_solve.log 2>&1; tail -1 $O/c4_full_solve.log | cut -c1-600
 cp gpurun_out/c4_full_solve_2000_4000.json $O/ 2>/dev/null
