@@ -90,6 +90,37 @@ def test_prepare_w_matches_oracle_and_identities(dev, m, cond):
     assert np.allclose(np.sort(out["DDsi"]), np.sort(sol.DDsi[0]), rtol=1e-8)
 
 
+@pytest.mark.parametrize("m,cond", [(400, 1e8), (700, 1e4)])
+def test_jacobi_early_stop_leaves_the_same_scaling(dev, m, cond):
+    """Option "jacobi_early": a sweep whose rotated column pairs were all closer to orthogonal than 3e-8 is the last one
+    (what it leaves is of second order) -- same W, D and NT identities as with the confirming sweep, one sweep fewer."""
+    import scipy.sparse as sp
+    X = _spd(m, 3, cond)
+    S = _spd(m, 4, cond)
+    A = [[sp.csc_matrix((m, m)), sp.identity(m, format="csc")]]
+    model = lo.make_model(A, np.ones(1), 0.0, None, None)
+    res = {}
+    try:
+        dev.set_option("jacobi_warm", 0)            # both runs from the same (cold) start
+        for early in (0.0, 3e-8):
+            dev.set_option("jacobi_early", early)
+            dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+            info, out = dev.prepare_w(0, X, S)
+            assert info == 0
+            res[early] = (out, dev.count("svd_sweeps"))
+    finally:
+        dev.set_option("jacobi_early", 3e-8)
+        dev.set_option("jacobi_warm", 1)
+    (full, sw_full), (early, sw_early) = res[0.0], res[3e-8]
+    assert sw_full - 2 <= sw_early <= sw_full, (sw_early, sw_full)      # (one fewer wherever the last sweep only confirms)
+    tol = 1e-14 * cond * m
+    assert relerr(early["W"], full["W"]) < 1e-13 * cond ** 0.5
+    assert np.allclose(np.sort(early["D"]), np.sort(full["D"]), rtol=1e-12)
+    W, G, D = early["W"], early["G"], early["D"]
+    assert relerr(W @ S @ W, X) < tol
+    assert relerr(G.T @ S @ G, np.diag(D)) < tol
+
+
 def test_prepare_w_reports_not_pd(dev):
     import scipy.sparse as sp
     m = 20
