@@ -75,7 +75,7 @@ struct LrnOptions {
   int jacobi_inner = 0;           // sweeps over the pair's Gram matrix per round (more did not cut the outer sweeps: 1)
   int jacobi_wgs = 0;             // workgroups per Gram / apply launch the row chunking aims for: 0 auto
   int jacobi_block = 0;           // column block width: 0 auto (32 for n >= 5000), 16, 32
-  int jacobi_cross = 1;           // 16-column block Jacobi: cross-pair rotations only outside round 0 of a sweep
+  int jacobi_cross = 1;           // block Jacobi: cross-pair rotations only outside round 0 of a sweep
   double jacobi_early = 3e-8;     // a sweep whose rotated column pairs were all closer to orthogonal than this ends the SVD
   bool jacobi_warm = true;
   int pair_lanes = 0;             // pair_wave_kernel: lanes per Schur entry, 0 auto (16 for short products), 16, 64

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void jb2_gram_kernel(const double* __restrict_
 // One (or `inner`) cyclic sweep(s) over the 64 x 64 Gram matrix: 63 steps of 32 disjoint rotations,
 // one thread per 2x2 block (pair k1 x pair k2), double-buffered, one barrier per step.
 __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restrict__ Gpart, int nchunk, int n, int nbk2,
-                                                          int round, double tol, double big2, int inner,
+                                                          int round, double tol, double big2, int inner, int full,
                                                           double* __restrict__ Rbuf,
                                                           int* __restrict__ flags, int* __restrict__ nrot) {
   extern __shared__ double jb2_sh[];
@@ -494,9 +494,12 @@ __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restri
     return;
   }
   if (t == 0) { anyrot = 0; anybig = 0; }
-  for (int e = t; e < 63 * 32; e += 1024) {
+  // `full` = 0: the 1024 cross pairs only, in 32 steps (as jb_rotate_kernel; the driver asks for all 63 in round 0)
+  const int nsteps = full ? 63 : 32;
+  for (int e = t; e < nsteps * 32; e += 1024) {
     int p, q;
-    rr_pair(64, e >> 5, e & 31, &p, &q);
+    if (full) rr_pair(64, e >> 5, e & 31, &p, &q);
+    else { p = e & 31; q = 32 + (((e & 31) + (e >> 5)) & 31); }
     sched[e >> 5][e & 31][0] = (unsigned char)p;
     sched[e >> 5][e & 31][1] = (unsigned char)q;
   }
@@ -517,8 +520,8 @@ __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restri
   double pc = 1.0, ps = 0.0;                          // R <- R J one step late, as in jb_rotate_kernel
   int pp = 0, pq = 0;
   const int src = (threadIdx.x & 0x20) | k1;          // lane of this wave with k2 == my k1
-  for (int istep = 0; istep < 63 * inner; ++istep) {
-    const int step = istep % 63;
+  for (int istep = 0; istep < nsteps * inner; ++istep) {
+    const int step = istep % nsteps;
     const int p1 = sched[step][k1][0], q1 = sched[step][k1][1];
     const int p2 = sched[step][k2][0], q2 = sched[step][k2][1];
     const double al = G[cur][p2][p2], be = G[cur][q2][q2], ga = G[cur][p2][q2];
@@ -668,7 +671,7 @@ int jacobi_svd(lrn_ctx* c, double* A, double* V, double* sigma, int n, int* swee
         if (wide) {
           hipLaunchKernelGGL(jb2_gram_kernel, dim3(npair, nchunk), dim3(256), 0, st, A, n, nbk2, round, RC, Gpart);
           hipLaunchKernelGGL(jb2_rotate_kernel, dim3(npair), dim3(1024), sh2, st, Gpart, nchunk, n, nbk2, round, tol,
-                             big2, inner, Rbuf, flags, cnt);
+                             big2, inner, (round == 0 || c->opt.jacobi_cross == 0) ? 1 : 0, Rbuf, flags, cnt);
           hipLaunchKernelGGL(jb2_apply_kernel, dim3(npair, nchunk, V ? 2 : 1), dim3(256), 0, st, A, V, n, nbk2, round, RC,
                              Rbuf, flags);
         } else {
