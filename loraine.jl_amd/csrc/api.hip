@@ -54,11 +54,13 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->redbuf);
   release(c->redout);
   release(c->lzbuf);
+  release(c->lzbuf2);
   release(c->lxbuf);
   release(c->ezbuf);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
   return LRN_OK;
 }
@@ -93,6 +95,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "matvec_sparse")) c->opt.matvec_sparse = (int)value;
   else if (!strcmp(key, "jacobi_cross")) c->opt.jacobi_cross = (int)value;
   else if (!strcmp(key, "jacobi_early")) c->opt.jacobi_early = value;
+  else if (!strcmp(key, "eigmin_pair")) c->opt.eigmin_pair = (int)value;
   else if (!strcmp(key, "jacobi_warm")) c->opt.jacobi_warm = value != 0.0;
   else if (!strcmp(key, "shard_bs")) { if (value < 0) return LRN_ERR_ARG; c->shard_bs_opt = (int)value; lrn::update_shard_bs(c); }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }

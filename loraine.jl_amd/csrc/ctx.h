@@ -76,6 +76,7 @@ struct LrnOptions {
   int jacobi_wgs = 0;             // workgroups per Gram / apply launch the row chunking aims for: 0 auto
   int jacobi_block = 0;           // column block width: 0 auto (32 for n >= 5000), 16, 32
   int jacobi_cross = 1;           // block Jacobi: cross-pair rotations only outside round 0 of a sweep
+  int eigmin_pair = 1;            // the two eigmin calls of a step-length search as interleaved Lanczos runs
   double jacobi_early = 3e-8;     // a sweep whose rotated column pairs were all closer to orthogonal than this ends the SVD
   bool jacobi_warm = true;
   int pair_lanes = 0;             // pair_wave_kernel: lanes per Schur entry, 0 auto (16 for short products), 16, 64
@@ -86,6 +87,7 @@ struct lrn_ctx {
   int device = 0;
   LrnOptions opt;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;      // second Lanczos run of eigmin_certified_pair (created on first use)
   std::string err;
   int nlmi = 0, nvar = 0, nlin = 0;
   std::vector<LmiBlock> lmi;
@@ -126,7 +128,7 @@ struct lrn_ctx {
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // generic scratch
-  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lxbuf, ezbuf;
+  lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lzbuf2, lxbuf, ezbuf;
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
 };

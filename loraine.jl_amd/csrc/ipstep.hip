@@ -253,9 +253,82 @@ static double ritz_residual(const std::vector<double>& a, const std::vector<doub
   return std::fabs(b[m - 1] * s[m - 1]);
 }
 
+// One Lanczos iteration as a resumable run: batches of 16 steps are queued on the run's stream, the (alpha, beta)
+// pairs come back in one copy per batch and the host decides on the tridiagonal matrix.  Two runs on two streams
+// interleave (eigmin_pair below): a step is two dependent launches of a few microseconds, so two independent
+// chains nearly halve the wall time of the two eigmin calls of a step-length search.
+struct LzRun {
+  const double* M = nullptr;
+  int n = 0;
+  hipStream_t st = nullptr;
+  double *q = nullptr, *qprev = nullptr, *w = nullptr, *ypart = nullptr, *ab = nullptr;
+  int nchunk = 1, cper = 1, mmax = 0, m = 0, m1 = 0;
+  std::vector<double> a, b, hab;
+  double theta = 0.0, theta_prev = 0.0, scale = 0.0;
+  bool have_prev = false, conv = false, done = false;
+};
+
+static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st, DBuf& buf) {
+  r.M = M; r.n = n; r.st = st;
+  // without re-orthogonalisation the extreme Ritz value may need more than n steps
+  r.mmax = std::min(1500, 4 * n + 40);
+  // column chunks of the symmetric mat-vec: ~64 columns per thread keeps the step kernel's reduction short
+  r.nchunk = std::max(1, std::min(64, n / 64));
+  r.cper = (n + r.nchunk - 1) / r.nchunk;
+  r.nchunk = (n + r.cper - 1) / r.cper;
+  LRN_TRY(ensure(c, buf, ((size_t)3 * n + (size_t)r.nchunk * n + 2 * (size_t)r.mmax + 64) * 8));
+  r.q = buf.as<double>();
+  r.qprev = r.q + n;
+  r.w = r.qprev + n;
+  r.ypart = r.w + n;
+  r.ab = r.ypart + (size_t)r.nchunk * n;
+  return LRN_OK;
+}
+
+// start vector (after lz_begin; a fresh workspace is zeroed on c->stream, which r.st must have waited for)
+static void lz_start(LzRun& r) {
+  hipLaunchKernelGGL(lz_init_kernel, dim3((r.n + 255) / 256), dim3(256), 0, r.st, r.q, r.n);
+  hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, r.st, r.ypart, r.nchunk, r.n, -1, r.q, r.qprev, r.w, r.ab);
+}
+
+static void lz_launch(LzRun& r) {
+  const int batch = r.n <= 16 ? r.n : 16;
+  r.m1 = std::min(r.mmax, r.m + batch);
+  for (int j = r.m; j < r.m1; ++j) {
+    hipLaunchKernelGGL(symv_part_kernel, dim3((r.n + 255) / 256, r.nchunk), dim3(256), 0, r.st, r.M, r.n, r.cper, r.q, r.ypart);
+    hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, r.st, r.ypart, r.nchunk, r.n, j, r.q, r.qprev, r.w, r.ab);
+  }
+}
+
+// waits for the batch in flight and decides: r.done when converged, settled or out of steps
+static int lz_collect(lrn_ctx* c, LzRun& r) {
+  const int m1 = r.m1;
+  r.hab.resize(2 * (size_t)m1);
+  LRN_HIP(c, hipMemcpyAsync(r.hab.data(), r.ab, (size_t)2 * m1 * 8, hipMemcpyDeviceToHost, r.st));
+  LRN_HIP(c, hipStreamSynchronize(r.st));
+  r.a.resize(m1); r.b.resize(m1);
+  int mm_ = m1;
+  for (int j = 0; j < m1; ++j) {
+    r.a[j] = r.hab[2 * j]; r.b[j] = r.hab[2 * j + 1];
+    r.scale = std::max(r.scale, std::fabs(r.a[j]) + std::fabs(r.b[j]));
+    if (!(r.b[j] > 1e-14 * r.scale) && j + 1 < m1) { mm_ = j + 1; break; }      // invariant subspace
+  }
+  r.theta = tridiag_min(r.a, r.b, mm_);
+  r.m = m1;
+  if (mm_ < m1) { r.conv = true; r.done = true; return LRN_OK; }
+  // stop on the rigorous residual bound; for a clearly non-negative spectrum (theta > 0 is an
+  // upper bound of lambda_min) the callers only need the sign class once theta has settled
+  const double res = ritz_residual(r.a, r.b, mm_, r.theta);
+  if (res <= 1e-11 * std::max(std::fabs(r.theta), 1e-4 * r.scale)) { r.conv = true; r.done = true; return LRN_OK; }
+  if (r.have_prev && r.theta > 0.0 && std::fabs(r.theta - r.theta_prev) <= 1e-3 * r.theta && r.m >= 64) { r.done = true; return LRN_OK; }
+  r.theta_prev = r.theta;
+  r.have_prev = true;
+  if (r.m >= r.mmax) r.done = true;
+  return LRN_OK;
+}
+
 int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, bool* converged = nullptr,
                double* scale_out = nullptr) {
-  hipStream_t st = c->stream;
   if (converged) *converged = true;
   if (scale_out) *scale_out = 0.0;
   if (n == 1) {
@@ -263,56 +336,43 @@ int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, 
     if (steps_out) *steps_out = 1;
     return LRN_OK;
   }
-  bool conv = false;
-  // without re-orthogonalisation the extreme Ritz value may need more than n steps
-  const int mmax = std::min(1500, 4 * n + 40);
-  // column chunks of the symmetric mat-vec: ~64 columns per thread keeps the step kernel's reduction short
-  int nchunk = std::max(1, std::min(64, n / 64));
-  const int cper = (n + nchunk - 1) / nchunk;
-  nchunk = (n + cper - 1) / cper;
-  LRN_TRY(ensure(c, c->lzbuf, ((size_t)3 * n + (size_t)nchunk * n + 2 * (size_t)mmax + 64) * 8));
-  double* q = c->lzbuf.as<double>();
-  double* qprev = q + n;
-  double* w = qprev + n;
-  double* ypart = w + n;
-  double* ab = ypart + (size_t)nchunk * n;
-  hipLaunchKernelGGL(lz_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, q, n);
-  hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, st, ypart, nchunk, n, -1, q, qprev, w, ab);
-  std::vector<double> a, b, hab;
-  double theta_prev = 0.0, theta = 0.0, scale = 0.0;
-  int m = 0;
-  bool have_prev = false;
-  const int batch = n <= 16 ? n : 16;
-  while (m < mmax) {
-    int m1 = std::min(mmax, m + batch);
-    for (int j = m; j < m1; ++j) {
-      hipLaunchKernelGGL(symv_part_kernel, dim3((n + 255) / 256, nchunk), dim3(256), 0, st, M, n, cper, q, ypart);
-      hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, st, ypart, nchunk, n, j, q, qprev, w, ab);
-    }
-    hab.resize(2 * (size_t)m1);
-    LRN_TRY(copy_out(c, hab.data(), ab, (size_t)2 * m1 * 8));
-    a.resize(m1); b.resize(m1);
-    int mm_ = m1;
-    for (int j = 0; j < m1; ++j) {
-      a[j] = hab[2 * j]; b[j] = hab[2 * j + 1];
-      scale = std::max(scale, std::fabs(a[j]) + std::fabs(b[j]));
-      if (!(b[j] > 1e-14 * scale) && j + 1 < m1) { mm_ = j + 1; break; }      // invariant subspace
-    }
-    theta = tridiag_min(a, b, mm_);
-    m = m1;
-    if (mm_ < m1) { conv = true; break; }
-    // stop on the rigorous residual bound; for a clearly non-negative spectrum (theta > 0 is an
-    // upper bound of lambda_min) the callers only need the sign class once theta has settled
-    double res = ritz_residual(a, b, mm_, theta);
-    if (res <= 1e-11 * std::max(std::fabs(theta), 1e-4 * scale)) { conv = true; break; }
-    if (have_prev && theta > 0.0 && std::fabs(theta - theta_prev) <= 1e-3 * theta && m >= 64) break;
-    theta_prev = theta;
-    have_prev = true;
+  LzRun r;
+  LRN_TRY(lz_begin(c, r, M, n, c->stream, c->lzbuf));
+  lz_start(r);
+  while (!r.done) {
+    lz_launch(r);
+    LRN_TRY(lz_collect(c, r));
   }
-  *lam = theta;
-  if (steps_out) *steps_out = m;
-  if (converged) *converged = conv;
-  if (scale_out) *scale_out = scale;
+  *lam = r.theta;
+  if (steps_out) *steps_out = r.m;
+  if (converged) *converged = r.conv;
+  if (scale_out) *scale_out = r.scale;
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
+// The Lanczos runs of two matrices of the same size side by side (second one on c->stream2, which first waits for
+// everything queued on c->stream): results as from two eigmin_dev calls.
+static int eigmin_dev_pair(lrn_ctx* c, const double* M1, const double* M2, int n, double lam[2], bool conv[2],
+                           double scale[2]) {
+  if (!c->stream2) LRN_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  LzRun r[2];
+  LRN_TRY(lz_begin(c, r[0], M1, n, c->stream, c->lzbuf));
+  LRN_TRY(lz_begin(c, r[1], M2, n, c->stream2, c->lzbuf2));
+  LRN_HIP(c, hipEventRecord(c->ev1, c->stream));             // the matrices, and the zeroing of a fresh workspace
+  LRN_HIP(c, hipStreamWaitEvent(c->stream2, c->ev1, 0));
+  lz_start(r[0]);
+  lz_start(r[1]);
+  lz_launch(r[0]);
+  lz_launch(r[1]);
+  while (!r[0].done || !r[1].done) {
+    for (int k = 0; k < 2; ++k) {
+      if (r[k].done) continue;
+      LRN_TRY(lz_collect(c, r[k]));          // (the other run's batch keeps the GPU busy meanwhile)
+      if (!r[k].done) lz_launch(r[k]);
+    }
+  }
+  for (int k = 0; k < 2; ++k) { lam[k] = r[k].theta; conv[k] = r[k].conv; scale[k] = r[k].scale; }
   LRN_HIP(c, hipGetLastError());
   return LRN_OK;
 }
@@ -345,10 +405,29 @@ static int chol_shift_is_pd(lrn_ctx* c, const double* M, int n, double shift, bo
   return LRN_OK;
 }
 
+static int eigmin_certify(lrn_ctx* c, const double* M, int n, double theta, bool conv, double scale, double* lam);
+
 int eigmin_certified(lrn_ctx* c, const double* M, int n, double* lam) {
   double theta = 0.0, scale = 0.0;
   bool conv = false;
   LRN_TRY(eigmin_dev(c, M, n, &theta, nullptr, &conv, &scale));
+  return eigmin_certify(c, M, n, theta, conv, scale, lam);
+}
+
+// eigmin_certified of two matrices of the same size: the two Lanczos runs interleaved, then the certificates
+int eigmin_certified_pair(lrn_ctx* c, const double* M1, const double* M2, int n, double* lam1, double* lam2) {
+  if (n == 1 || !c->opt.eigmin_pair) {
+    LRN_TRY(eigmin_certified(c, M1, n, lam1));
+    return eigmin_certified(c, M2, n, lam2);
+  }
+  double th[2], sc[2];
+  bool cv[2];
+  LRN_TRY(eigmin_dev_pair(c, M1, M2, n, th, cv, sc));
+  LRN_TRY(eigmin_certify(c, M1, n, th[0], cv[0], sc[0], lam1));
+  return eigmin_certify(c, M2, n, th[1], cv[1], sc[1], lam2);
+}
+
+static int eigmin_certify(lrn_ctx* c, const double* M, int n, double theta, bool conv, double scale, double* lam) {
   static const bool trace = getenv("LRN_EIGMIN_TRACE") != nullptr;
   if (trace) fprintf(stderr, "[eigmin n=%d] theta=%.12g conv=%d scale=%.3g\n", n, theta, (int)conv, scale);
   if (n == 1) { *lam = theta; return LRN_OK; }
@@ -554,11 +633,11 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
     LRN_TRY(mm(c, m, Gi, false, b.delX.as<double>(), false, t0));
     LRN_TRY(mm(c, m, t0, false, Gi, true, t1));
     hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t2, m);
-    LRN_TRY(eigmin_certified(c, t2, m, &lamX));
+    double* t3 = b.Xn.as<double>();          // free here: Xn / Sn are rebuilt by lrn_ip_update after the step lengths
     LRN_TRY(mm(c, m, G, true, b.delS.as<double>(), false, t0));
     LRN_TRY(mm(c, m, t0, false, G, false, t1));
-    hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t2, m);
-    LRN_TRY(eigmin_certified(c, t2, m, &lamS));
+    hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t3, m);
+    LRN_TRY(eigmin_certified_pair(c, t2, t3, m, &lamX, &lamS));
     alpha[il] = lamX > -1e-6 ? 0.99 : std::min(1.0, -tau / lamX);
     beta[il] = lamS > -1e-6 ? 0.99 : std::min(1.0, -tau / lamS);
   }
@@ -625,8 +704,7 @@ extern "C" int lrn_ip_stats(lrn_ctx* c, double* out5) {
   for (int il = 0; il < c->nlmi; ++il) {
     LmiBlock& b = c->lmi[il];
     double lx = 0, ls = 0;
-    LRN_TRY(eigmin_certified(c, b.X.as<double>(), b.msz, &lx));
-    LRN_TRY(eigmin_certified(c, b.S.as<double>(), b.msz, &ls));
+    LRN_TRY(eigmin_certified_pair(c, b.X.as<double>(), b.S.as<double>(), b.msz, &lx, &ls));
     out5[5 * il + 1] = lx;
     out5[5 * il + 2] = ls;
     out5[5 * il + 3] = std::sqrt(out5[5 * il + 3]);
