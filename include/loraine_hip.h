@@ -76,7 +76,8 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * GEMM3' in chunks of 16, 0 = off), "pair_lanes" (lanes per entry of the sparse pair kernel: 0 auto / 4 / 8 / 16 / 64),
  * "jacobi_cross" (1: cross-pair rotations only after round 0), "jacobi_early" (relative level below which a sweep's
  * rotations make it the last one; 0 = always run the confirming sweep), "eigmin_pair" (1: the two
- * smallest-eigenvalue searches of a step-length computation as interleaved Lanczos runs on two streams), "reset_timing". */
+ * smallest-eigenvalue searches of a step-length computation as interleaved Lanczos runs on two streams),
+ * "prepw_streams" (1: lrn_prepare_w runs the S side and the Gi solve on a second stream), "reset_timing". */
 int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
 /* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */
 int lrn_set_shard(lrn_ctx* ctx, int rank, int world);

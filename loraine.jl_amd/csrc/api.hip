@@ -59,6 +59,8 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->ezbuf);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  if (c->evA) (void)hipEventDestroy(c->evA);
+  if (c->evB) (void)hipEventDestroy(c->evB);
   (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -96,6 +98,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "jacobi_cross")) c->opt.jacobi_cross = (int)value;
   else if (!strcmp(key, "jacobi_early")) c->opt.jacobi_early = value;
   else if (!strcmp(key, "eigmin_pair")) c->opt.eigmin_pair = (int)value;
+  else if (!strcmp(key, "prepw_streams")) c->opt.prepw_streams = (int)value;
   else if (!strcmp(key, "jacobi_warm")) c->opt.jacobi_warm = value != 0.0;
   else if (!strcmp(key, "shard_bs")) { if (value < 0) return LRN_ERR_ARG; c->shard_bs_opt = (int)value; lrn::update_shard_bs(c); }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }

@@ -76,6 +76,7 @@ struct LrnOptions {
   int jacobi_wgs = 0;             // workgroups per Gram / apply launch the row chunking aims for: 0 auto
   int jacobi_block = 0;           // column block width: 0 auto (32 for n >= 5000), 16, 32
   int jacobi_cross = 1;           // block Jacobi: cross-pair rotations only outside round 0 of a sweep
+  int prepw_streams = 1;          // prepare_W: the S side and the Gi solve on a second stream beside cholesky(X) / the SVD / the GEMMs
   int eigmin_pair = 1;            // the two eigmin calls of a step-length search as interleaved Lanczos runs
   double jacobi_early = 3e-8;     // a sweep whose rotated column pairs were all closer to orthogonal than this ends the SVD
   bool jacobi_warm = true;
@@ -127,6 +128,7 @@ struct lrn_ctx {
   std::map<std::string, long> counts;
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evA = nullptr, evB = nullptr;      // stream <-> stream2 dependencies (prepare_w_block)
   // generic scratch
   lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lzbuf2, lxbuf, ezbuf;
   // preconditioner / CG state

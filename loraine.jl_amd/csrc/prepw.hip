@@ -97,36 +97,69 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   const int n = b.msz;
   const size_t mm = (size_t)n * n * 8;
   hipStream_t st = c->stream;
-  // workspace: LX, LS, CC/tmp, V, Y  (5 n^2) + Linv blocks x2 + chol work
+  // workspace: LX, LS, CC/tmp, V, Y, Y2  (6 n^2) + Linv blocks x2 + chol / trsm work x2
   size_t linv = chol_linv_doubles(n);
-  size_t need = (5 * (size_t)n * n + 2 * linv + (size_t)n * CHOL_NB + (size_t)CHOL_NB * n + 4 * (size_t)n) * 8;
+  size_t need = (6 * (size_t)n * n + 2 * linv + 2 * ((size_t)n * CHOL_NB + (size_t)CHOL_NB * n) + 4 * (size_t)n) * 8;
   LRN_TRY(ensure(c, c->scratch, need));
   double* LX = c->scratch.as<double>();
   double* LS = LX + (size_t)n * n;
   double* CC = LS + (size_t)n * n;
   double* V = CC + (size_t)n * n;
   double* Y = V + (size_t)n * n;
-  double* LinvX = Y + (size_t)n * n;
+  double* Y2 = Y + (size_t)n * n;
+  double* LinvX = Y2 + (size_t)n * n;
   double* LinvS = LinvX + linv;
   double* cw = LinvS + linv;              // n*NB
   double* tw = cw + (size_t)n * CHOL_NB;  // NB*n
+  double* cw2 = tw + (size_t)CHOL_NB * n;
+  double* tw2 = cw2 + (size_t)n * CHOL_NB;
+  LRN_TRY(ensure(c, c->info_dev, 64));
   int* dinfo = c->info_dev.as<int>();
+  int* dinfoS = dinfo + 12;
   *info = 0;
-  // Cholesky of X and S
+  // Two streams (option "prepw_streams"): the S side -- cholesky(S), then Si = LS^-T LS^-1, which nothing before the
+  // end needs -- runs beside cholesky(X) and the Jacobi SVD, whose launches leave most of the chip idle; after the SVD
+  // the triangular solve for Gi runs beside the GEMMs for G, W and DDsi.
+  const bool two = c->opt.prepw_streams != 0;
+  hipStream_t s2 = st;
+  if (two) {
+    if (!c->stream2) LRN_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!c->evA) {
+      LRN_HIP(c, hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
+      LRN_HIP(c, hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
+    }
+    s2 = c->stream2;
+    LRN_HIP(c, hipEventRecord(c->evA, st));                   // X, S (and the workspace) are ready
+    LRN_HIP(c, hipStreamWaitEvent(s2, c->evA, 0));
+  }
+  // Cholesky of X (stream) and S (second stream)
   LRN_HIP(c, hipMemcpyAsync(LX, b.X.p, mm, hipMemcpyDeviceToDevice, st));
   LRN_HIP(c, hipMemsetAsync(dinfo, 0, 4, st));
   LRN_TRY(potrf_lower(st, LX, n, n, LinvX, cw, dinfo));
-  int h = 0;
-  LRN_HIP(c, hipMemcpyAsync(&h, dinfo, 4, hipMemcpyDeviceToHost, st));
-  LRN_HIP(c, hipStreamSynchronize(st));
-  if (h != 0) { *info = 1; return LRN_OK; }
-  LRN_HIP(c, hipMemcpyAsync(LS, b.S.p, mm, hipMemcpyDeviceToDevice, st));
-  LRN_TRY(potrf_lower(st, LS, n, n, LinvS, cw, dinfo));
-  LRN_HIP(c, hipMemcpyAsync(&h, dinfo, 4, hipMemcpyDeviceToHost, st));
-  LRN_HIP(c, hipStreamSynchronize(st));
-  if (h != 0) { *info = 2; return LRN_OK; }
   hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, LX, n);
-  hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, LS, n);
+  LRN_HIP(c, hipMemcpyAsync(LS, b.S.p, mm, hipMemcpyDeviceToDevice, s2));
+  LRN_HIP(c, hipMemsetAsync(dinfoS, 0, 4, s2));
+  LRN_TRY(potrf_lower(s2, LS, n, n, LinvS, two ? cw2 : cw, dinfoS));
+  hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, s2, LS, n);
+  if (two) LRN_HIP(c, hipEventRecord(c->evB, s2));            // LS is final
+  // Si = LS^-T LS^-1   (on the second stream: overlaps everything up to the end of this function)
+  hipLaunchKernelGGL(eye_kernel, dim3(nb2((long)n * n)), dim3(256), 0, s2, Y2, n);
+  LRN_TRY(trsm_left_lower(s2, LS, n, n, LinvS, false, Y2, n, n, two ? tw2 : tw));
+  LRN_TRY(gemm_nn(s2, n, Y2, true, Y2, false, b.Si.as<double>(), GEMM_TRI_LOWER));
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb2((long)n * n)), dim3(256), 0, s2, b.Si.as<double>(), n);
+  // the verdicts, in the reference's order: X first (prepare_W.jl:33), then S (:34)
+  int h[2] = {0, 0};
+  LRN_HIP(c, hipMemcpyAsync(&h[0], dinfo, 4, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipStreamSynchronize(st));
+  if (two) LRN_HIP(c, hipEventSynchronize(c->evB));
+  else LRN_HIP(c, hipStreamSynchronize(st));
+  LRN_HIP(c, hipMemcpy(&h[1], dinfoS, 4, hipMemcpyDeviceToHost));
+  if (h[0] != 0 || h[1] != 0) {
+    if (two) LRN_HIP(c, hipStreamSynchronize(s2));            // nothing of this call may still run when the caller retries
+    *info = h[0] != 0 ? 1 : 2;
+    return LRN_OK;
+  }
+  if (two) LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
   // SVD of CC = LS' LX = U D V' by one-sided Jacobi on CC' = LX' LS: its columns are rotated by
   // U and converge to V D, so V = (columns / D) needs no accumulation of rotations -- the rounds
   // are bandwidth-bound (every round streams the whole matrix), this removes the V half of it.
@@ -147,6 +180,14 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   c->counts["svd_sweeps"] = sweeps;
   toc(c, "prepw_svd");
   tic(c);
+  // Gi' = LX^-T (V D^1/2)   (second stream: beside the GEMMs below; V, D and Y are free from here on)
+  if (two) {
+    LRN_HIP(c, hipEventRecord(c->evA, st));
+    LRN_HIP(c, hipStreamWaitEvent(s2, c->evA, 0));
+  }
+  hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, s2, V, b.D.as<double>(), n, 1, Y);
+  LRN_TRY(trsm_left_lower(s2, LX, n, n, LinvX, true, Y, n, n, two ? tw2 : tw));
+  hipLaunchKernelGGL(transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, s2, Y, n, b.Gi.as<double>());
   // G = LX (V D^-1/2)
   hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 0, CC);
   LRN_TRY(gemm_nn(st, n, LX, false, CC, false, b.G.as<double>()));
@@ -157,21 +198,16 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
                        b.Vprev.as<double>());
     b.have_Vprev = true;
   }
-  // Gi' = LX^-T (V D^1/2)
-  hipLaunchKernelGGL(scale_cols_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, V, b.D.as<double>(), n, 1, Y);
-  LRN_TRY(trsm_left_lower(st, LX, n, n, LinvX, true, Y, n, n, tw));
-  hipLaunchKernelGGL(transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, st, Y, n, b.Gi.as<double>());
   // W = G G'
   LRN_TRY(gemm_nn(st, n, b.G.as<double>(), false, b.G.as<double>(), true, b.W.as<double>(), GEMM_TRI_LOWER));
   hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, b.W.as<double>(), n);
-  // Si = LS^-T LS^-1
-  hipLaunchKernelGGL(eye_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, Y, n);
-  LRN_TRY(trsm_left_lower(st, LS, n, n, LinvS, false, Y, n, n, tw));
-  LRN_TRY(gemm_nn(st, n, Y, true, Y, false, b.Si.as<double>(), GEMM_TRI_LOWER));
-  hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, b.Si.as<double>(), n);
   // DDsi = 1/sqrt(diag(G' S G))
   LRN_TRY(gemm_nn(st, n, b.S.as<double>(), false, b.G.as<double>(), false, CC));
   hipLaunchKernelGGL(coldot_rsqrt_kernel, dim3(n), dim3(256), 0, st, b.G.as<double>(), CC, n, b.DDsi.as<double>());
+  if (two) {                                                  // join: Si and Gi are complete when this call returns
+    LRN_HIP(c, hipEventRecord(c->evB, s2));
+    LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
+  }
   toc(c, "prepw_gemm");
   LRN_HIP(c, hipGetLastError());
   b.have_W = b.have_G = true;
