@@ -46,9 +46,9 @@ def test_lanczos_eigmin(dev, n, kind):
         assert (got > -1e-6) == (ref > -1e-6), (got, ref, steps)
 
 
-def _run(path, resident, **opts):
+def _run(path, resident, device=None, **opts):
     from loraine_jl_amd.optimizer import Optimizer
-    o = Optimizer(resident=resident)
+    o = Optimizer(resident=resident, device=device)        # (options are per context: pass the configured one)
     o.set_silent(True)
     for k, v in opts.items():
         o.set_attribute(k, v)
@@ -112,12 +112,32 @@ def test_resident_equals_host_driver(name, opts):
     assert abs(a.solver.iter - b.solver.iter) <= 1
 
 
+@pytest.mark.parametrize("name,opts", [("control1", dict(kit=0)), ("maxG11", dict(kit=0, datarank=-1))])
+def test_second_stream_changes_nothing(dev, name, opts):
+    """Options "prepw_streams" (S side of prepare_W beside the SVD) and "eigmin_pair" (the two Lanczos runs of a
+    step-length search interleaved): the same kernels on the same data in the same order per buffer -- every
+    iteration's objectives are bit-identical with and without."""
+    path = os.path.join(GOLD, f"{name}.dat-s")
+    runs = []
+    for on in (0, 1):
+        dev.set_option("prepw_streams", on)
+        dev.set_option("eigmin_pair", on)
+        try:
+            o = _run(path, True, device=dev, **opts)
+        finally:
+            dev.set_option("prepw_streams", 1)
+            dev.set_option("eigmin_pair", 1)
+        assert o.termination_status() == "OPTIMAL"
+        runs.append([(t["primal_obj"], t["dual_obj"], t["dimacs"]) for t in o.solver.trace])
+    assert runs[0] == runs[1]
+
+
 @pytest.mark.parametrize("eig", [1, 2])
 def test_thetaG11_resident_pcg(dev, eig):
     # prec_eig 1: eig(W) by Jacobi (the reference's full `eigen`); 2: Lanczos extremes only
     dev.set_option("prec_eig", eig)
     try:
-        o = _run(os.path.join(GOLD, "thetaG11.dat-s"), True, kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
+        o = _run(os.path.join(GOLD, "thetaG11.dat-s"), True, device=dev, kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)
     finally:
         dev.set_option("prec_eig", 0)
     assert o.termination_status() == "OPTIMAL"
