@@ -67,9 +67,11 @@ def main():
     # per-context options on the device every solve runs on: FUZZ_SCHUR_CHOL=1 takes the Cholesky-factor assembly paths regardless of size
     # (1: <L'A_iL, L'A_jL> where every constraint of a block is dense, T_k = L (L'A_kL) L' otherwise; 2: the latter
     # only), FUZZ_DENSE=1 stores every non-empty constraint matrix dense
-    if os.environ.get("FUZZ_SCHUR_CHOL") or os.environ.get("FUZZ_DENSE"):
+    if os.environ.get("FUZZ_SCHUR_CHOL") or os.environ.get("FUZZ_DENSE") or os.environ.get("FUZZ_STRICT"):
         import loraine_jl_amd
         _d = loraine_jl_amd.Device(0)
+        if os.environ.get("FUZZ_STRICT"):            # the literal reference behaviour on non-positive pivots
+            _d.set_option("pivot_boost", 0)
         if os.environ.get("FUZZ_SCHUR_CHOL"):
             _d.set_option("schur_chol", int(os.environ["FUZZ_SCHUR_CHOL"]))
         if os.environ.get("FUZZ_DENSE"):
@@ -97,7 +99,7 @@ def main():
                 try:
                     o.optimize(); gs, go, gi = o.solver.status, o.objective_value(), o.solver.iter
                 except Exception as e:
-                    gs, go, gi = "exc:" + type(e).__name__, None, None
+                    gs, go, gi = "exc:" + type(e).__name__ + ":" + str(e)[:80], None, None
                 # status must agree; objective and iteration count are compared for solved problems only
                 ok = gs == rs and (rs != 1 or (abs(go - ro) <= 1e-6 * (1 + abs(ro)) and abs(gi - ri) <= 1))
                 if not ok:
