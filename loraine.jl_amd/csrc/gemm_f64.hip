@@ -447,6 +447,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   const bool mir = EPI && (d.flags & GEMM_C_MIRROR) && (tm != tn);
   const int pkS = packed_S(d.pk_m);
   const long pkKd = packed_diag_elems(d.pk_m > 0 ? d.pk_m : 1);
+  if (pk && !sq) {
+    // Packed lower C, chunk-major: a 16x16 block (column block q, row block rb >= q of the symmetric matrix) is 16
+    // chunks of 16 doubles, chunk(c, rb) = c for the diagonal block and Kd/16 + [q S - 8 q (q+1)] + cc (S/16 - q - 1) +
+    // (rb - q - 1) below it (packed_lower_offset / 16 with c = 16 q + cc) -- block-uniform terms hoisted, two integer
+    // operations per element (the generic offset function per element cost GEMM2' 3 % in its epilogue)
+    const long S16 = pkS >> 4, kd16 = pkKd >> 4;
+    const int qb = (m0 + d.pk_off) >> 4, rbb = (n0 + d.pk_off) >> 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long q = qb + 2 * i + wm;
+      const long below = kd16 + q * pkS - 8 * q * (q + 1) - q - 1;      // + cc * (S16 - q - 1) + rb
+      const long percol = S16 - q - 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!(smask & (1u << (i * 4 + j)))) continue;
+        const long rb = rbb + 2 * j + wn;
+        if (rb < q) continue;                     // 16x16 blocks on and below the diagonal only
+        const int n = n0 + (2 * j + wn) * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = MFMA_F64_ROW(lane, r);
+          const int m = m0 + (2 * i + wm) * 16 + cc;
+          if (m < d.M && n < d.N) {
+            const long chunk = rb == q ? 16 * q + cc : below + cc * percol + rb;
+            Cg[chunk * d.pk_cstride + fr] = alpha * acc[i][j][r];
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -459,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
         if (m < d.M && n < d.N) {
           double v = alpha * acc[i][j][r];
           if (sq) v = v * v;
-          if (pk) {                               // 16x16 blocks on and below the diagonal only
+          if (pk) {                               // (only with GEMM_SQUARE: the generic offset function)
             if ((n >> 4) >= (m >> 4)) {
               const long o = packed_lower_offset(n + d.pk_off, m + d.pk_off, pkS, pkKd);
               Cg[(o >> 4) * d.pk_cstride + (o & 15)] = v;
