@@ -186,6 +186,14 @@ int lrn_dbg_eigmin(lrn_ctx* ctx, int n, const double* M, double* lam, int* steps
 int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top, double* U_top,
                     double* lam_min, double* trace, int* steps);
 
+/* copy one msz x msz (or msz) array of the resident state of block il to `out` (tests of the scaling):
+ * name = "W", "Si", "G", "Gi", "D", "DDsi" (valid after the SVD route), "X", "S", "delX", "delS", "RNT",
+ * and, after the eigen-free route (option "nt_mode" = 1, the default of lrn_ip_prepare_w; src/prepare_W.jl:28-94
+ * without the singular vectors): "LX", "LXi", "LS", "LSi" (Cholesky factors and their inverses), "Yh", "Zh"
+ * ((K/c)^1/2, (K/c)^-1/2 for K = L_X' S L_X), "Qm" (G RNT G' of the predictor).  *flag (may be NULL) receives 1 when the
+ * current scaling of the block is the eigen-free one, and c = lrn_get_timing("ns_c") its scale. */
+int lrn_dbg_get_block(lrn_ctx* ctx, int il, const char* name, double* out, int* flag);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* milliseconds of the named phase in the last call that ran it, measured with HIP events
  * on the context's stream ("gemm1","gemm2","gemm3","sparse","assemble","factor","solve",...);

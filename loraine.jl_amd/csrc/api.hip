@@ -100,6 +100,11 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "eigmin_pair")) c->opt.eigmin_pair = (int)value;
   else if (!strcmp(key, "prepw_streams")) c->opt.prepw_streams = (int)value;
   else if (!strcmp(key, "jacobi_warm")) c->opt.jacobi_warm = value != 0.0;
+  else if (!strcmp(key, "nt_mode")) c->opt.nt_mode = (int)value;
+  else if (!strcmp(key, "ns_l0")) c->opt.ns_l0 = value;
+  else if (!strcmp(key, "ns_maxit")) c->opt.ns_maxit = (int)value;
+  else if (!strcmp(key, "lyap_tol")) c->opt.lyap_tol = value;
+  else if (!strcmp(key, "lyap_maxit")) c->opt.lyap_maxit = (int)value;
   else if (!strcmp(key, "shard_bs")) { if (value < 0) return LRN_ERR_ARG; c->shard_bs_opt = (int)value; lrn::update_shard_bs(c); }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }
   else return set_error(c, LRN_ERR_ARG, "unknown option %s", key);
@@ -123,6 +128,8 @@ int lrn_set_scaling(lrn_ctx* c, int il, const double* W, const double* G) {
   size_t mm = (size_t)b.msz * b.msz * 8;
   LRN_TRY(copy_in(c, b.W.p, W, mm));
   b.have_W = true;
+  b.have_G = false;
+  b.nt_free = false;
   if (G) {
     LRN_TRY(copy_in(c, b.G.p, G, mm));
     b.have_G = true;

@@ -661,7 +661,8 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
   for (int il = 0; il < c->nlmi; ++il) {
     LmiBlock& b = c->lmi[il];
     const int m = b.msz, k = erank;
-    if (!b.have_G) return set_error(c, LRN_ERR_STATE, "preconditioner setup needs G (lrn_prepare_w)");
+    if (!b.have_G && !b.have_W) return set_error(c, LRN_ERR_STATE, "preconditioner setup needs G or W (lrn_prepare_w)");
+    const bool fromW = !b.have_G;     // eigen-free scaling: eig(W) from W itself (its singular values ARE its eigenvalues)
     if (k >= m) return set_error(c, LRN_ERR_ARG, "erank >= matrix size");
     size_t mm = (size_t)m * m * 8;
     LRN_TRY(ensure(c, P->E, mm));
@@ -691,7 +692,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
         be[il].coef[a] = std::sqrt(std::max(lam_top[a] - tau, 0.0));
       }
     } else {
-      LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
+      LRN_HIP(c, hipMemcpyAsync(P->E.p, fromW ? b.W.p : b.G.p, mm, hipMemcpyDeviceToDevice, st));
       int sweeps = 0;
       // eig(W) = svd(G)^2 : columns of E become sigma_j u_j   (Solvers.jl:642,706)
       LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sweeps));
@@ -700,15 +701,16 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
       std::vector<int> ord(m);
       for (int i = 0; i < m; ++i) ord[i] = i;
       std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sg[x] < sg[y]; });   // ascending
+      auto lam_of = [&](int i) { return fromW ? sg[i] : sg[i] * sg[i]; };
       std::vector<double> lam_s(m - k);
-      for (int i = 0; i < m - k; ++i) lam_s[i] = sg[ord[i]] * sg[ord[i]];
+      for (int i = 0; i < m - k; ++i) lam_s[i] = lam_of(ord[i]);
       double tau = tau_of(lam_s, aamat);
       be[il].tau = tau;
-      for (int i = 0; i < m; ++i) be[il].trace += sg[i] * sg[i];
+      for (int i = 0; i < m; ++i) be[il].trace += lam_of(i);
       if (aamat < 3) dsum += tau * tau;
       for (int a = 0; a < k; ++a) {
         int id = ord[m - k + a];
-        double lam = sg[id] * sg[id];
+        double lam = lam_of(id);
         be[il].idx[a] = id;
         be[il].coef[a] = std::sqrt(std::max(lam - tau, 0.0)) / sg[id];   // Umat = v_l sqrt(lambda_l - tau)
       }
@@ -757,7 +759,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
           double lmn, trc;
           LRN_TRY(lanczos_extremes(c, b.W.as<double>(), m, k, lt.data(), P->E.as<double>(), &lmn, &trc, nullptr));
         } else {
-          LRN_HIP(c, hipMemcpyAsync(P->E.p, b.G.p, mm, hipMemcpyDeviceToDevice, st));
+          LRN_HIP(c, hipMemcpyAsync(P->E.p, b.have_G ? b.G.p : b.W.p, mm, hipMemcpyDeviceToDevice, st));
           int sw = 0;
           LRN_TRY(jacobi_svd(c, P->E.as<double>(), nullptr, P->sig.as<double>(), m, &sw));
         }

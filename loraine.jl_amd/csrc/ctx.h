@@ -50,6 +50,13 @@ struct LmiBlock {
   bool resident = false;
   bool have_Vprev = false;
   bool have_W = false, have_G = false;
+  // --- eigen-free NT scaling (prepw.hip::prepare_w_ns, option nt_mode = 1): L_X and its transpose, Yh = (K/c)^1/2,
+  // Zh = (K/c)^-1/2, Ki = (K/c)^-1 for K = L_X' S L_X; per direction Bs = L_X' dS L_X, TX = L_X^-1 dX L_X^-T;
+  // Qm = G RNT G' of the predictor; Lyapunov-CG work; dense copy of the rank-one factors
+  lrn::DBuf LXf, LXt, Yh, Zh, Ki, Bs, TX, Qm, lyap, Bd;
+  double ns_c = 1.0;        // the scale c of K (host copy)
+  bool nt_free = false;     // the current scaling came from prepare_w_ns: G, Gi, D, DDsi are NOT valid
+  bool have_Bd = false;     // dense copy of the rank-one factors (rank-one assembly from W)
 };
 
 struct lrn_ctx;
@@ -80,6 +87,12 @@ struct LrnOptions {
   int eigmin_pair = 1;            // the two eigmin calls of a step-length search as interleaved Lanczos runs
   double jacobi_early = 3e-8;     // a sweep whose rotated column pairs were all closer to orthogonal than this ends the SVD
   bool jacobi_warm = true;
+  int nt_mode = 1;                // lrn_ip_prepare_w: 1 = eigen-free NT scaling (Newton-Schulz square roots of K = L_X'SL_X, Lyapunov
+                                  // solve for the second-order term; falls back to the SVD when it does not converge), 0 = SVD always
+  double ns_l0 = 1e-3;            // Newton-Schulz schedule: assumed lower end of spec(K)/c (slower, never wrong, when cond(K) is larger)
+  int ns_maxit = 40;              // Newton-Schulz steps before the SVD fallback
+  double lyap_tol = 1e-12;        // relative residual of the Lyapunov CG (second-order term of the corrector)
+  int lyap_maxit = 300;
   int pair_lanes = 0;             // pair_wave_kernel: lanes per Schur entry, 0 auto (16 for short products), 16, 64
   int matvec_sparse = 0;          // 0 auto, 1 dense GEMM path, 2 sparse path whenever the pattern allows
 };

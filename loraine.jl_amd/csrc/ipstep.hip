@@ -77,6 +77,18 @@ __global__ void corr_inner_kernel(const double* __restrict__ GRG, const double* 
   }
 }
 
+// TX = -I - T (+ a Ki + R): L_X^-1 dX L_X^-T in the eigen-free scaling (a = sigma_mu / c, Ki = (K/c)^-1; R may be null)
+__global__ void tx_kernel(const double* __restrict__ T, double a, const double* __restrict__ Ki, const double* __restrict__ R,
+                          double* __restrict__ out, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    double v = -T[e];
+    if ((int)(e % n) == (int)(e / n)) v -= 1.0;
+    if (R) v += a * Ki[e] + R[e];
+    out[e] = v;
+  }
+}
+
 __global__ void add_diag_mat_kernel(double* __restrict__ M, int n, double eps) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) M[(long)i * n + i] += eps;
@@ -465,6 +477,134 @@ static int eigmin_certify(lrn_ctx* c, const double* M, int n, double theta, bool
   return LRN_OK;
 }
 
+// ------------------------------------------------------------------ Lyapunov solve (eigen-free NT scaling)
+// out = scale (T + T') by 32 x 32 tiles (both reads coalesced); with `dotp`: part[block] = sum dotp .* out over the block's
+// tiles.  out is exactly symmetric: (i,j) and (j,i) add the same two numbers.
+__global__ __launch_bounds__(256) void symadd_kernel(const double* __restrict__ T, int n, double scale, double* __restrict__ out,
+                                                     const double* __restrict__ dotp, double* __restrict__ part) {
+  __shared__ double ta[32][33], tb[32][33];
+  __shared__ double sh[4];
+  const int nt = (n + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  double acc = 0.0;
+  for (long t = blockIdx.x; t < (long)nt * nt; t += gridDim.x) {
+    const int bi = (int)(t % nt) * 32, bj = (int)(t / nt) * 32;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int i = bi + tx, j = bj + r;       // tile (bi, bj): element (i, j)
+      ta[r][tx] = (i < n && j < n) ? T[(long)i + (long)j * n] : 0.0;
+      const int i2 = bj + tx, j2 = bi + r;     // tile (bj, bi): element (i2, j2)
+      tb[r][tx] = (i2 < n && j2 < n) ? T[(long)i2 + (long)j2 * n] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int i = bi + tx, j = bj + r;
+      if (i < n && j < n) {
+        const double v = scale * (ta[r][tx] + tb[tx][r]);      // T[i,j] + T[j,i]
+        out[(long)i + (long)j * n] = v;
+        if (dotp) acc += dotp[(long)i + (long)j * n] * v;
+      }
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ double block_sum_parts(const double* __restrict__ part, int np, double* sh) {
+  double s = 0.0;
+  for (int e = threadIdx.x; e < np; e += 256) s += part[e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// alpha = rr_k / <p, Ap> (every workgroup sums the same partials in the same order); R += alpha p; r -= alpha Ap;
+// part2[block] = sum r^2
+__global__ __launch_bounds__(256) void lyap_xr_kernel(const double* __restrict__ part1, int np1, const double* __restrict__ hist,
+                                                      int k, const double* __restrict__ p, const double* __restrict__ Ap,
+                                                      double* __restrict__ R, double* __restrict__ r, long total,
+                                                      double* __restrict__ part2) {
+  __shared__ double sh[4];
+  const double pAp = block_sum_parts(part1, np1, sh);
+  const double rr = hist[k];
+  const double alpha = (pAp > 0.0 && rr > 0.0) ? rr / pAp : 0.0;
+  double s = 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    R[e] += alpha * p[e];
+    const double v = r[e] - alpha * Ap[e];
+    r[e] = v;
+    s += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part2[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// beta = rr_{k+1} / rr_k; p = r + beta p; hist[k+1] = rr_{k+1}
+__global__ __launch_bounds__(256) void lyap_p_kernel(const double* __restrict__ part2, int np2, double* __restrict__ hist, int k,
+                                                     const double* __restrict__ r, double* __restrict__ p, long total) {
+  __shared__ double sh[4];
+  const double rn = block_sum_parts(part2, np2, sh);
+  const double rr = hist[k];
+  const double beta = rr > 0.0 ? rn / rr : 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) p[e] = r[e] + beta * p[e];
+  if (blockIdx.x == 0 && threadIdx.x == 0) hist[k + 1] = rn;
+}
+
+// R with Yh R + R Yh = Cm (Yh symmetric positive definite, Cm symmetric) by conjugate gradients in the Frobenius inner
+// product: one product Yh p per step (the other half of the operator is its transpose), all scalars stay on the device,
+// the host reads the residual history once per batch of steps.  Cm is used as the residual and destroyed.
+static int lyap_solve(lrn_ctx* c, LmiBlock& b, double* Cm, double* R, double* work, bool* ok, int* steps) {
+  const int n = b.msz;
+  const long nn = (long)n * n;
+  hipStream_t st = c->stream;
+  const int maxit = std::max(8, c->opt.lyap_maxit);
+  const int np = (int)std::min<long>(1024, (nn + 255) / 256);
+  LRN_TRY(ensure(c, b.lyap, ((size_t)2 * nn + 2 * 1024 + maxit + 16) * 8));
+  double* p = b.lyap.as<double>();
+  double* Ap = p + nn;
+  double* part1 = Ap + nn;
+  double* part2 = part1 + 1024;
+  double* hist = part2 + 1024;
+  double* r = Cm;
+  LRN_HIP(c, hipMemsetAsync(R, 0, (size_t)nn * 8, st));
+  LRN_HIP(c, hipMemcpyAsync(p, r, (size_t)nn * 8, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(dot_part_kernel, dim3(np), dim3(256), 0, st, r, (const double*)nullptr, nn, part1);
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, part1, np, hist);
+  std::vector<double> h(maxit + 1, 0.0);
+  const double tol2 = c->opt.lyap_tol * c->opt.lyap_tol;
+  int k = 0;
+  *ok = false;
+  const int ntile = (n + 31) / 32;
+  const int np1 = (int)std::min<long>(1024, (long)ntile * ntile);
+  while (k < maxit) {
+    const int k1 = std::min(maxit, k + (k == 0 ? 8 : 4));
+    for (; k < k1; ++k) {
+      LRN_TRY(gemm_nt(st, n, b.Yh.as<double>(), p, work));
+      hipLaunchKernelGGL(symadd_kernel, dim3(np1), dim3(256), 0, st, work, n, 1.0, Ap, p, part1);
+      hipLaunchKernelGGL(lyap_xr_kernel, dim3(np), dim3(256), 0, st, part1, np1, hist, k, p, Ap, R, r, nn, part2);
+      hipLaunchKernelGGL(lyap_p_kernel, dim3(np), dim3(256), 0, st, part2, np, hist, k, r, p, nn);
+    }
+    LRN_HIP(c, hipMemcpyAsync(h.data(), hist, (size_t)(k + 1) * 8, hipMemcpyDeviceToHost, st));
+    LRN_HIP(c, hipStreamSynchronize(st));
+    if (!(h[k] == h[k])) break;                                   // NaN
+    if (h[0] == 0.0 || h[k] <= tol2 * h[0]) { *ok = true; break; }
+  }
+  if (steps) *steps = k;
+  return LRN_OK;
+}
+
 // ------------------------------------------------------------------ resident step
 static int ensure_resident(lrn_ctx* c, LmiBlock& b) {
   size_t mm_ = (size_t)b.msz * b.msz * 8;
@@ -522,7 +662,12 @@ extern "C" int lrn_ip_prepare_w(lrn_ctx* c, int il, int* info) {
   if (!info) return LRN_ERR_ARG;
   hipEvent_t a0, a1;
   if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
-  LRN_TRY(prepare_w_block(c, b, info));
+  bool conv = false;
+  if (c->opt.nt_mode == 1 && b.msz > 1) LRN_TRY(prepare_w_ns(c, b, info, &conv));
+  if (!conv && *info == 0) {
+    b.nt_free = false;
+    LRN_TRY(prepare_w_block(c, b, info));
+  }
   if (c->profile) {
     (void)hipEventRecord(a1, c->stream); (void)hipEventSynchronize(a1);
     float ms = 0; (void)hipEventElapsedTime(&ms, a0, a1);
@@ -580,6 +725,16 @@ extern "C" int lrn_ip_rhs_corr(lrn_ctx* c, double sigma_mu, double* out) {
     LRN_TRY(ensure_resident(c, b));
     const int m = b.msz;
     const long mm_ = (long)m * m;
+    if (b.nt_free) {
+      // G (G'RdG + D - sigma_mu/D - RNT) G' = W Rd W + X - sigma_mu Si - G RNT G'
+      LRN_TRY(wmw(c, b, b.Rd.as<double>(), b.t1.as<double>(), b.t2.as<double>()));
+      hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t0.as<double>(), 1.0, b.t2.as<double>(), 1.0,
+                         b.X.as<double>(), -sigma_mu, b.Si.as<double>(), mm_);
+      hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t2.as<double>(), 1.0, b.t0.as<double>(), -1.0,
+                         b.Qm.as<double>(), 0.0, (const double*)nullptr, mm_);
+      LRN_TRY(aa_times(c, b, b.t2.as<double>(), c->v1.as<double>()));
+      continue;
+    }
     double* G = b.G.as<double>();
     // t1 = G' Rd G
     LRN_TRY(mm(c, m, G, true, b.Rd.as<double>(), false, b.t0.as<double>()));
@@ -613,6 +768,29 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
     LRN_TRY(aat_to_mat(c, b, c->v0.as<double>(), t0));
     hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, b.delS.as<double>(), 1.0, b.Rd.as<double>(), -1.0, t0,
                        0.0, (const double*)nullptr, mm_);
+    double lamX = 0.0, lamS = 0.0;
+    double* t3 = b.Xn.as<double>();          // free here: Xn / Sn are rebuilt by lrn_ip_update after the step lengths
+    if (b.nt_free) {
+      // everything in the L_X basis (prepw.hip::prepare_w_ns): Bs = L_X' dS L_X, T = Z Bs Z / c,
+      // TX = L_X^-1 dX L_X^-T = -I - T (+ sigma_mu K^-1 + R), dX = L_X TX L_X'                  (:253-257)
+      const unsigned gs = (unsigned)std::min<long>(1024, ((long)(m + 31) / 32) * ((m + 31) / 32));
+      LRN_TRY(gemm_nt(c->stream, m, b.LXt.as<double>(), b.delS.as<double>(), t0));
+      LRN_TRY(gemm_nt(c->stream, m, t0, b.LXt.as<double>(), t1));
+      hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, b.Bs.as<double>(), (const double*)nullptr,
+                         (double*)nullptr);
+      LRN_TRY(gemm_nt(c->stream, m, b.Zh.as<double>(), b.Bs.as<double>(), t0));
+      LRN_TRY(gemm_nt(c->stream, m, t0, b.Zh.as<double>(), t1, 0, 1.0 / b.ns_c));
+      hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, t3, (const double*)nullptr, (double*)nullptr);
+      hipLaunchKernelGGL(tx_kernel, dim3(g), dim3(256), 0, c->stream, t3, sigma_mu / b.ns_c, b.Ki.as<double>(),
+                         predict ? (const double*)nullptr : b.RNT.as<double>(), b.TX.as<double>(), m);
+      LRN_TRY(gemm_nt(c->stream, m, b.LXf.as<double>(), b.TX.as<double>(), t0));
+      LRN_TRY(gemm_nt(c->stream, m, t0, b.LXf.as<double>(), b.delX.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR));
+      // the scaled directions of the step-length rule are orthogonally similar to TX and T               (:263-285)
+      LRN_TRY(eigmin_certified_pair(c, b.TX.as<double>(), t3, m, &lamX, &lamS));
+      alpha[il] = lamX > -1e-6 ? 0.99 : std::min(1.0, -tau / lamX);
+      beta[il] = lamS > -1e-6 ? 0.99 : std::min(1.0, -tau / lamS);
+      continue;
+    }
     // t2 = W delS W                                                (:253)
     LRN_TRY(wmw(c, b, b.delS.as<double>(), t1, t2));
     if (predict) {
@@ -629,11 +807,9 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
     }
     hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.delX.as<double>(), m);
     // step lengths: eigmin of DDsi-scaled G' delS G and Gi delX Gi'   (:263-291)
-    double lamX = 0.0, lamS = 0.0;
     LRN_TRY(mm(c, m, Gi, false, b.delX.as<double>(), false, t0));
     LRN_TRY(mm(c, m, t0, false, Gi, true, t1));
     hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t2, m);
-    double* t3 = b.Xn.as<double>();          // free here: Xn / Sn are rebuilt by lrn_ip_update after the step lengths
     LRN_TRY(mm(c, m, G, true, b.delS.as<double>(), false, t0));
     LRN_TRY(mm(c, m, t0, false, G, false, t1));
     hipLaunchKernelGGL(scale_sym_kernel, dim3(g), dim3(256), 0, c->stream, t1, b.DDsi.as<double>(), t3, m);
@@ -667,12 +843,39 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
                          b.delX.as<double>(), 0.0, (const double*)nullptr, mm_);
       hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, b.Sn.as<double>(), 1.0, b.S.as<double>(), beta[il],
                          b.delS.as<double>(), 0.0, (const double*)nullptr, mm_);
+      LRN_TRY(dot_dev(c, b.Xn.as<double>(), b.Sn.as<double>(), mm_, c->redout.as<double>() + il));
+      if (b.nt_free) {
+        // Qm = G RNT G' without the eigenvectors: N = L_X^-1 dX dS L_X = TX Bs, Yh R + R Yh = -(N Zh + Zh N') / c,
+        // Qm = L_X R L_X'
+        tic(c);
+        LRN_TRY(gemm_nt(c->stream, m, b.TX.as<double>(), b.Bs.as<double>(), t0));              // N
+        LRN_TRY(gemm_nt(c->stream, m, t0, b.Zh.as<double>(), t1));                             // N Zh
+        hipLaunchKernelGGL(symadd_kernel, dim3((unsigned)std::min<long>(1024, ((long)(m + 31) / 32) * ((m + 31) / 32))), dim3(256), 0,
+                           c->stream, t1, m, -1.0 / b.ns_c, t2, (const double*)nullptr, (double*)nullptr);
+        bool ok = false;
+        int steps = 0;
+        LRN_TRY(lyap_solve(c, b, t2, b.RNT.as<double>(), t0, &ok, &steps));
+        c->counts["lyap_steps"] += steps;
+        c->counts["lyap_solves"] += 1;
+        if (ok) {
+          LRN_TRY(gemm_nt(c->stream, m, b.LXf.as<double>(), b.RNT.as<double>(), t0));
+          LRN_TRY(gemm_nt(c->stream, m, t0, b.LXf.as<double>(), b.Qm.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR));
+          toc(c, "lyap");
+          continue;
+        }
+        // the Lyapunov iteration did not converge (K far from well conditioned): take the SVD for this iteration
+        toc(c, "lyap");
+        c->counts["lyap_fallback"] += 1;
+        int info = 0;
+        LRN_TRY(prepare_w_block(c, b, &info));
+        if (info != 0) return set_error(c, LRN_ERR_STATE, "SVD fallback of the NT scaling failed (info %d)", info);
+        b.nt_free = false;
+      }
       // RNT = -(Gi delX delS G + its transpose) ./ (D_i + D_j)     (:308-309)
       LRN_TRY(mm(c, m, b.Gi.as<double>(), false, b.delX.as<double>(), false, t0));
       LRN_TRY(mm(c, m, t0, false, b.delS.as<double>(), false, t1));
       LRN_TRY(mm(c, m, t1, false, b.G.as<double>(), false, t2));
       hipLaunchKernelGGL(rnt_kernel, dim3(g), dim3(256), 0, c->stream, t2, b.D.as<double>(), b.RNT.as<double>(), m);
-      LRN_TRY(dot_dev(c, b.Xn.as<double>(), b.Sn.as<double>(), mm_, c->redout.as<double>() + il));
     } else {
       hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, b.X.as<double>(), alpha[0],
                          b.delX.as<double>(), 0.0, (const double*)nullptr, mm_);
@@ -710,6 +913,26 @@ extern "C" int lrn_ip_stats(lrn_ctx* c, double* out5) {
     out5[5 * il + 3] = std::sqrt(out5[5 * il + 3]);
   }
   return LRN_OK;
+}
+
+extern "C" int lrn_dbg_get_block(lrn_ctx* c, int il, const char* name, double* out, int* flag) {
+  if (!c || il < 0 || il >= c->nlmi || !name || !out) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  LmiBlock& b = c->lmi[il];
+  const size_t mm_ = (size_t)b.msz * b.msz * 8, mv = (size_t)b.msz * 8;
+  struct { const char* n; DBuf* d; size_t bytes; } tab[] = {
+      {"W", &b.W, mm_}, {"Si", &b.Si, mm_}, {"G", &b.G, mm_}, {"Gi", &b.Gi, mm_}, {"D", &b.D, mv}, {"DDsi", &b.DDsi, mv},
+      {"X", &b.X, mm_}, {"S", &b.S, mm_}, {"delX", &b.delX, mm_}, {"delS", &b.delS, mm_}, {"RNT", &b.RNT, mm_},
+      {"LX", &b.LXf, mm_}, {"Bs", &b.Bs, mm_}, {"TX", &b.TX, mm_}, {"Ki", &b.Ki, mm_}, {"Yh", &b.Yh, mm_},
+      {"Zh", &b.Zh, mm_}, {"Qm", &b.Qm, mm_}};
+  if (flag) *flag = b.nt_free ? 1 : 0;
+  c->timing["ns_c"] = b.ns_c;
+  for (auto& t : tab)
+    if (!strcmp(name, t.n)) {
+      if (!t.d->p || t.d->bytes < t.bytes) return set_error(c, LRN_ERR_STATE, "block array %s not allocated", name);
+      return copy_out(c, out, t.d->p, t.bytes);
+    }
+  return set_error(c, LRN_ERR_ARG, "unknown block array %s", name);
 }
 
 extern "C" int lrn_dbg_eigmin(lrn_ctx* c, int n, const double* M, double* lam, int* steps) {

@@ -211,6 +211,283 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   toc(c, "prepw_gemm");
   LRN_HIP(c, hipGetLastError());
   b.have_W = b.have_G = true;
+  b.nt_free = false;
+  return LRN_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Eigen-free NT scaling (round 3).  The reference takes an SVD of L_S'L_X (prepare_W.jl:39-64) to get G, Gi, D; what
+// the iteration consumes of them can be written with K = L_X' S L_X = V D^2 V' alone:
+//   W = G G' = L_X K^-1/2 L_X'                                   (prepare_W.jl:64)
+//   with B = L_X' dS L_X, T = K^-1/2 B K^-1/2, TX = L_X^-1 dX L_X^-T = -I - T (+ sm K^-1 + R in the corrector):
+//   dX = L_X TX L_X' (predictor_corrector.jl:255,257); the scaled directions of the step-length rule (:263-285) are
+//   orthogonally similar to TX and T (DDsi.*(Gi dX Gi').*DDsi = V' TX V, DDsi.*(G' dS G).*DDsi = V' T V), same eigmin;
+//   G RNT G' (:186, :257, :309) = L_X R L_X' with K^1/2 R + R K^1/2 = -(N K^-1/2 + K^-1/2 N'), N = L_X^-1 dX dS L_X = TX B
+//   G (G'RdG + D - sm/D - RNT) G' (:186) = W Rd W + X - sm Si - L_X R L_X'
+// Nothing is inverted: products with an explicit L_X^-1 lose the directions through cancellation once cond(X) passes
+// 1e10 (control1 left the trajectory at iteration 21 that way); in the L_X basis every term is O(1).
+// K is well conditioned along a solve (D^2 = eig(XS) stays near the central path: cond(K) <~ 1e3 where cond(X) reaches
+// 1e12), so Y = (K/c)^1/2 and Z = (K/c)^-1/2 come from the coupled Newton-Schulz iteration -- products only, on the MFMA:
+//   P = Z Y, T = a (3 I - a^2 P)/2, Y <- Y T, Z <- T Z,
+// with the one-sided scaling a = sqrt(3/(1 + l + l^2)), l <- a l (3 - a^2 l^2)/2 for spec(P)^1/2 in [l, 1]: the map never
+// leaves (0, 1], so a wrong guess of l costs steps, never correctness.  c = min(||K||_1, ||K||_F) >= lambda_max(K).
+// The steps are queued without host round trips; ||I - P||_F of every step comes back in one copy.
+// tools/nt_eigenfree_proto.py emulates the whole route in NumPy against the SVD route of the oracle.
+__global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__ K, int n, double* __restrict__ colsum,
+                                                      double* __restrict__ colsq) {
+  __shared__ double sh[8];
+  const double* a = K + (long)blockIdx.x * n;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { double v = a[i]; s += fabs(v); q += v * v; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[w] = s; sh[4 + w] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    colsum[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    colsq[blockIdx.x] = sh[4] + sh[5] + sh[6] + sh[7];
+  }
+}
+
+// sc[0] = c = min(max_j colsum_j, sqrt(sum_j colsq_j)), sc[1] = 1/c   (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void normc_kernel(const double* __restrict__ colsum, const double* __restrict__ colsq,
+                                                    int n, double* __restrict__ sc) {
+  __shared__ double shm[4], shq[4];
+  double mx = 0.0, q = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) { mx = fmax(mx, colsum[j]); q += colsq[j]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mx = fmax(mx, __shfl_down(mx, off, 64)); q += __shfl_down(q, off, 64); }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { shm[w] = mx; shq[w] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m1 = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+    double fr = sqrt(shq[0] + shq[1] + shq[2] + shq[3]);
+    double cc = fmin(m1, fr);
+    if (!(cc > 0.0)) cc = 1.0;
+    sc[0] = cc;
+    sc[1] = 1.0 / cc;
+  }
+}
+
+__global__ void scale_dev_kernel(const double* __restrict__ K, const double* __restrict__ sc, long total,
+                                 double* __restrict__ Y) {
+  const double f = sc[1];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) Y[e] = K[e] * f;
+}
+
+// T = a (3 I - a^2 P) / 2;  part[block] = sum (delta_ij - P_ij)^2 over the block's elements
+__global__ __launch_bounds__(256) void ns_t_kernel(const double* __restrict__ P, int n, double a, double* __restrict__ T,
+                                                   double* __restrict__ part) {
+  __shared__ double sh[4];
+  const long total = (long)n * n;
+  const double a3 = 0.5 * a * a * a, a1 = 1.5 * a;
+  double s = 0.0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const double p = P[e];
+    const bool dg = (e % n) == (e / n);
+    const double r = (dg ? 1.0 : 0.0) - p;
+    s += r * r;
+    T[e] = (dg ? a1 : 0.0) - a3 * p;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void sum_sqrt_kernel(const double* __restrict__ part, int np, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int e = threadIdx.x; e < np; e += 256) s += part[e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// C = alpha A Bm'  (all n x n column-major): both operands contiguous along the result's dimensions -> direct-to-LDS kernel
+int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags, double alpha) {
+  GemmDesc g;
+  g.A = A; g.sAm = 1; g.sAk = n;
+  g.B = Bm; g.sBk = n; g.sBn = 1;
+  g.C = C; g.sCm = 1; g.sCn = n;
+  g.M = g.N = g.K = n;
+  g.alpha = alpha;
+  g.flags = flags;
+  return gemm(st, g);
+}
+
+int symm_prod(hipStream_t st, int n, const double* A, const double* B, double* C, double alpha) {
+  // lower tiles + mirror only pays once the lower tiles alone fill the chip (n >= 3000: 300 tiles of 128)
+  return gemm_nt(st, n, A, B, C, n >= 3000 ? (GEMM_TRI_LOWER | GEMM_C_MIRROR) : 0, alpha);
+}
+
+int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
+  const int n = b.msz;
+  const size_t nn = (size_t)n * n, mm = nn * 8;
+  hipStream_t st = c->stream;
+  *info = 0;
+  *converged = false;
+  b.nt_free = false;
+  for (DBuf* d : {&b.LXf, &b.LXt, &b.Yh, &b.Zh, &b.Ki, &b.Bs, &b.TX, &b.Qm}) LRN_TRY(ensure(c, *d, mm));
+  size_t linv = chol_linv_doubles(n);
+  const int npart = (int)std::min<size_t>(1024, (nn + 255) / 256);
+  const int maxit = std::max(4, std::min(c->opt.ns_maxit, 120));
+  // scratch: P, T, Ya, Za, L_S, L_S^-1, L_S^-T (7 n^2), Linv blocks x2, chol / trsm work x2, column norms, partial sums, residuals
+  size_t need = (7 * nn + 2 * linv + 2 * ((size_t)n * CHOL_NB + (size_t)CHOL_NB * n) + 2 * (size_t)n + npart + maxit + 64) * 8;
+  LRN_TRY(ensure(c, c->scratch, need));
+  double* LXt = b.LXt.as<double>();
+  double* Pm = c->scratch.as<double>();
+  double* Tm = Pm + nn;
+  double* Ya = Tm + nn;
+  double* Za = Ya + nn;
+  double* LS = Za + nn;
+  double* LSi = LS + nn;
+  double* LSit = LSi + nn;
+  double* LinvX = LSit + nn;
+  double* LinvS = LinvX + linv;
+  double* cw = LinvS + linv;
+  double* tw = cw + (size_t)n * CHOL_NB;
+  double* cw2 = tw + (size_t)CHOL_NB * n;
+  double* tw2 = cw2 + (size_t)n * CHOL_NB;
+  double* colsum = tw2 + (size_t)CHOL_NB * n;
+  double* colsq = colsum + n;
+  double* part = colsq + n;
+  double* res = part + npart;        // res[0..maxit), then sc[0..1]
+  double* sc = res + maxit;
+  double* LX = b.LXf.as<double>();
+  LRN_TRY(ensure(c, c->info_dev, 64));
+  int* dinfo = c->info_dev.as<int>();
+  int* dinfoS = dinfo + 12;
+  if (!c->stream2) LRN_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  if (!c->evA) {
+    LRN_HIP(c, hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
+    LRN_HIP(c, hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
+  }
+  hipStream_t s2 = c->opt.prepw_streams ? c->stream2 : st;
+  const bool two = s2 != st;
+  const unsigned ge = nb2((long)nn);
+  if (two) {
+    LRN_HIP(c, hipEventRecord(c->evA, st));
+    LRN_HIP(c, hipStreamWaitEvent(s2, c->evA, 0));
+  }
+  tic(c);
+  // X side: L_X, its transpose, its inverse
+  LRN_HIP(c, hipMemcpyAsync(LX, b.X.p, mm, hipMemcpyDeviceToDevice, st));
+  LRN_HIP(c, hipMemsetAsync(dinfo, 0, 4, st));
+  LRN_TRY(potrf_lower(st, LX, n, n, LinvX, cw, dinfo));
+  hipLaunchKernelGGL(tril_kernel, dim3(ge), dim3(256), 0, st, LX, n);
+  // S side (second stream): L_S, its inverse, Si = L_S^-T L_S^-1                       (prepare_W.jl:34,68)
+  LRN_HIP(c, hipMemcpyAsync(LS, b.S.p, mm, hipMemcpyDeviceToDevice, s2));
+  LRN_HIP(c, hipMemsetAsync(dinfoS, 0, 4, s2));
+  LRN_TRY(potrf_lower(s2, LS, n, n, LinvS, two ? cw2 : cw, dinfoS));
+  hipLaunchKernelGGL(tril_kernel, dim3(ge), dim3(256), 0, s2, LS, n);
+  // the verdicts first, in the reference's order (prepare_W.jl:33-34): nothing else is queued on a failed factor
+  int h[2] = {0, 0};
+  LRN_HIP(c, hipMemcpyAsync(&h[0], dinfo, 4, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipMemcpyAsync(&h[1], dinfoS, 4, hipMemcpyDeviceToHost, s2));
+  LRN_HIP(c, hipStreamSynchronize(st));
+  if (two) LRN_HIP(c, hipStreamSynchronize(s2));
+  if (h[0] != 0 || h[1] != 0) {
+    *info = h[0] != 0 ? 1 : 2;
+    return LRN_OK;
+  }
+  toc(c, "prepw_chol");
+  tic(c);
+  const dim3 tg((n + 31) / 32, (n + 31) / 32), tb(32, 8);
+  double* LSt = Za;                                  // (free until the second Newton-Schulz step, which st orders after its reader)
+  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LS, n, LSt);
+  if (two) LRN_HIP(c, hipEventRecord(c->evB, s2));
+  hipLaunchKernelGGL(eye_kernel, dim3(ge), dim3(256), 0, s2, LSi, n);
+  LRN_TRY(trsm_left_lower(s2, LS, n, n, LinvS, false, LSi, n, n, two ? tw2 : tw));
+  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LSi, n, LSit);   // L_S^-T
+  LRN_TRY(gemm_nt(s2, n, LSit, LSit, b.Si.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0));
+  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, LX, n, LXt);
+  // K = CC' CC with CC = L_S' L_X (prepare_W.jl:39) -- NOT L_X' S L_X: with cond(X), cond(S) at 1e10 the entries of
+  // |L_X'| |S| |L_X| are 1e10 times those of K and the explicit product has no correct digit left (measured: the
+  // Newton-Schulz iteration then diverges); through the factors the error is that of CC itself, which the SVD shares
+  double* Y = b.Yh.as<double>();
+  double* Z = b.Zh.as<double>();
+  if (two) LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
+  LRN_TRY(gemm_nt(st, n, LXt, LSt, Pm, 0, 1.0));                                      // CC' = L_X' L_S
+  LRN_TRY(gemm_nt(st, n, Pm, Pm, Tm, GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0));           // K = CC' CC
+  hipLaunchKernelGGL(colnorm_kernel, dim3(n), dim3(256), 0, st, Tm, n, colsum, colsq);
+  hipLaunchKernelGGL(normc_kernel, dim3(1), dim3(256), 0, st, colsum, colsq, n, sc);
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ge), dim3(256), 0, st, Tm, sc, (long)nn, Y);
+  toc(c, "prepw_gemm");
+  tic(c);
+  // Newton-Schulz: the planned steps are the scaled ones plus the plain steps of the quadratic phase
+  double ell = std::sqrt(std::min(std::max(c->opt.ns_l0, 1e-12), 0.25));
+  double* Yc = Y; double* Yn = Ya;
+  double* Zc = Z; double* Zn = Za;
+  bool z_is_eye = true;
+  int k = 0;
+  auto one_step = [&](double a) -> int {
+    const double* Pk = Yc;
+    if (!z_is_eye) { LRN_TRY(symm_prod(st, n, Zc, Yc, Pm)); Pk = Pm; }
+    hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Pk, n, a, Tm, part);
+    hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, part, npart, res + k);
+    LRN_TRY(symm_prod(st, n, Yc, Tm, Yn));
+    std::swap(Yc, Yn);
+    if (z_is_eye) {
+      LRN_HIP(c, hipMemcpyAsync(Zc, Tm, mm, hipMemcpyDeviceToDevice, st));
+      z_is_eye = false;
+    } else {
+      LRN_TRY(symm_prod(st, n, Tm, Zc, Zn));
+      std::swap(Zc, Zn);
+    }
+    ++k;
+    return LRN_OK;
+  };
+  while (k < maxit && 1.0 - ell > 1e-9) {
+    const double a = std::sqrt(3.0 / (1.0 + ell + ell * ell));
+    ell = 0.5 * a * ell * (3.0 - a * a * ell * ell);
+    LRN_TRY(one_step(a));
+  }
+  if (k < maxit) LRN_TRY(one_step(1.0));
+  std::vector<double> hres(maxit + 2, 0.0);
+  bool ok = false;
+  for (;;) {
+    LRN_HIP(c, hipMemcpyAsync(hres.data(), res, (size_t)(maxit + 2) * 8, hipMemcpyDeviceToHost, st));
+    LRN_HIP(c, hipStreamSynchronize(st));
+    const double rl = hres[k - 1];           // ||I - P|| at the START of the last step: the step squares it
+    if (!(rl == rl) || rl > 1e30) break;     // NaN / overflow: not a matrix this iteration handles
+    if (rl <= 3e-8) { ok = true; break; }
+    if (k + 2 > maxit) break;
+    LRN_TRY(one_step(1.0));
+    LRN_TRY(one_step(1.0));
+  }
+  c->counts["ns_steps"] = k;
+  toc(c, "prepw_ns");
+  if (!ok) {
+    if (two) LRN_HIP(c, hipStreamSynchronize(s2));
+    c->counts["ns_fallback"] += 1;
+    return LRN_OK;
+  }
+  tic(c);
+  b.ns_c = hres[maxit];
+  if (Yc != Y) LRN_HIP(c, hipMemcpyAsync(Y, Yc, mm, hipMemcpyDeviceToDevice, st));
+  if (Zc != Z) LRN_HIP(c, hipMemcpyAsync(Z, Zc, mm, hipMemcpyDeviceToDevice, st));
+  // W = L_X K^-1/2 L_X' = L_X Z L_X' / sqrt(c)                                          (prepare_W.jl:64)
+  LRN_TRY(gemm_nt(st, n, LX, Z, Pm, 0, 1.0));
+  LRN_TRY(gemm_nt(st, n, Pm, LX, b.W.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0 / std::sqrt(b.ns_c)));
+  // (K/c)^-1 = Zh^2: the sigma_mu S^-1 term of the corrector in the L_X basis
+  LRN_TRY(symm_prod(st, n, Z, Z, b.Ki.as<double>()));
+  if (two) {                                                  // join: Si is complete when this returns
+    LRN_HIP(c, hipEventRecord(c->evB, s2));
+    LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
+  }
+  toc(c, "prepw_gemm");
+  LRN_HIP(c, hipGetLastError());
+  b.have_W = true;
+  b.have_G = false;
+  b.nt_free = true;
+  *converged = true;
   return LRN_OK;
 }
 

@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256) void bg_kernel(const long* __restrict__ bptr, 
   }
 }
 
+// Bdt[k + h*msz] = B[h, k]  (dense copy of the rank-one factors, zero-filled by the caller)
+__global__ void b_dense_kernel(const long* __restrict__ bptr, const int* __restrict__ bcol, const double* __restrict__ bval,
+                               int msz, double* __restrict__ Bdt) {
+  const int h = blockIdx.x;
+  for (long f = bptr[h] + threadIdx.x; f < bptr[h + 1]; f += blockDim.x) Bdt[(long)bcol[f] + (long)h * msz] = bval[f];
+}
+
 // H += C_lin diag(xs) C_lin'  (lower triangle): one thread per target entry sums its contributions in
 // a fixed order (lists built at upload) -- no floating-point atomics, results are reproducible
 __global__ void lin_schur_kernel(const int* __restrict__ pr, const int* __restrict__ pc, const long* __restrict__ pp,
@@ -880,11 +887,21 @@ static int assemble_sparse(lrn_ctx* c, LmiBlock& b) {
 static int assemble_rank1(lrn_ctx* c, LmiBlock& b) {
   const int n = c->nvar, m = b.msz;
   if (!b.has_B) return set_error(c, LRN_ERR_STATE, "rank-one mode requested but no B factors were uploaded");
-  if (!b.have_G) return set_error(c, LRN_ERR_STATE, "rank-one mode needs G (lrn_prepare_w / lrn_set_scaling)");
+  // with G: H = ((BG)(BG)').^2 as the reference forms it (makeBBBB.jl:7-14); after the eigen-free scaling only W = GG'
+  // exists: H = ((BW) B').^2 against a dense copy of B -- the same matrix
+  const bool fromW = !b.have_G;
+  if (fromW && !b.have_W) return set_error(c, LRN_ERR_STATE, "rank-one mode needs G or W (lrn_prepare_w / lrn_set_scaling)");
   LRN_TRY(ensure(c, c->BG, (size_t)m * n * 8));
+  if (fromW && !b.have_Bd) {
+    LRN_TRY(ensure(c, b.Bd, (size_t)m * n * 8));
+    LRN_HIP(c, hipMemsetAsync(b.Bd.p, 0, (size_t)m * n * 8, c->stream));
+    hipLaunchKernelGGL(b_dense_kernel, dim3(n), dim3(64), 0, c->stream, b.b_ptr.as<long>(), b.b_col.as<int>(),
+                       b.b_val.as<double>(), m, b.Bd.as<double>());
+    b.have_Bd = true;
+  }
   tic(c);
   hipLaunchKernelGGL(bg_kernel, dim3(n), dim3(256), 0, c->stream, b.b_ptr.as<long>(), b.b_col.as<int>(),
-                     b.b_val.as<double>(), b.G.as<double>(), m, c->BG.as<double>());
+                     b.b_val.as<double>(), fromW ? b.W.as<double>() : b.G.as<double>(), m, c->BG.as<double>());
   // owned column blocks of the lower triangle (all of it on one GPU)
   std::vector<std::pair<int, int>> cols;
   if (c->world > 1) {
@@ -897,7 +914,7 @@ static int assemble_rank1(lrn_ctx* c, LmiBlock& b) {
     const int c0 = cb.first, c1 = cb.second;
     GemmDesc g;     // H[c0:, c0:c1] += ((BG BG')[c0:, c0:c1]).^2, lower tiles of the sub-block
     g.A = c->BG.as<double>() + (long)c0 * m; g.sAm = m; g.sAk = 1;
-    g.B = c->BG.as<double>() + (long)c0 * m; g.sBk = 1; g.sBn = m;
+    g.B = (fromW ? b.Bd.as<double>() : c->BG.as<double>()) + (long)c0 * m; g.sBk = 1; g.sBn = m;
     g.C = c->H.as<double>() + (long)c0 + (long)c0 * n; g.sCm = 1; g.sCn = n;
     g.M = n - c0; g.N = c1 - c0; g.K = m;
     g.beta = 1.0;

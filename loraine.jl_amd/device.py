@@ -309,6 +309,14 @@ class Device:
         self._chk(self.lib.lrn_ip_get_iterate(self.h, ilmi, ptr(X), ptr(S)), "lrn_ip_get_iterate")
         return X, S
 
+    def dbg_get_block(self, ilmi, name):
+        """One array of the resident state of a block (see lrn_dbg_get_block); returns (array, eigen_free_flag)."""
+        m = self.msizes[ilmi]
+        out = np.zeros(m) if name in ("D", "DDsi") else np.zeros((m, m), order="F")
+        flag = C.c_int(0)
+        self._chk(self.lib.lrn_dbg_get_block(self.h, ilmi, name.encode(), ptr(out), C.byref(flag)), "lrn_dbg_get_block")
+        return out, flag.value
+
     def ip_add_diag(self, ilmi, which, eps):
         self._chk(self.lib.lrn_ip_add_diag(self.h, ilmi, int(which), float(eps)), "lrn_ip_add_diag")
 
