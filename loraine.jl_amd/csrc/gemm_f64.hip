@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmParams p) {
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
           if (mir) Cg[(long)n * d.sCm + (long)m * d.sCn] = v;
+          if (EPI && d.C2) d.C2[(long)n * d.sCm + (long)m * d.sCn] = v;      // transposed copy (square C, batch 1)
         }
       }
 }
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
           if (d.beta != 0.0) v += d.beta * (*c);
           *c = v;
           if (mir) Cg[(long)n * d.sCm + (long)m * d.sCn] = v;
+          if (EPI && d.C2) d.C2[(long)n * d.sCm + (long)m * d.sCn] = v;      // transposed copy (square C, batch 1)
         }
       }
     }
@@ -955,7 +957,8 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   const bool bkc = (d.sBk == 1 && d.sBn != 1);
   dim3 grid(ntile, 1, d.batch * d.ksplit);
   if (grid.z > 65535) return gemm_fail(LRN_ERR_ARG, "gemm: grid.z > 65535");
-  const bool epi = d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE | GEMM_C_PACKED | GEMM_C_MIRROR);
+  const bool epi = (d.flags & (GEMM_OFFDIAG_X2 | GEMM_SQUARE | GEMM_C_PACKED | GEMM_C_MIRROR)) || d.C2;
+  if (d.C2 && (d.M != d.N || d.batch != 1 || d.ksplit != 1 || kseg)) return gemm_fail(LRN_ERR_ARG, "gemm: C2 needs a square, unbatched, unsplit product");
   if (kflat) {
     if (big) {
       static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5>,

@@ -94,6 +94,7 @@ struct GemmDesc {
   const double* A = nullptr;
   const double* B = nullptr;
   double* C = nullptr;
+  double* C2 = nullptr;     // optional: the transposed result as well (same strides as C; square, unbatched products)
   int M = 0, N = 0, K = 0;
   long sAm = 0, sAk = 0, sBk = 0, sBn = 0, sCm = 0, sCn = 0;
   long bA = 0, bB = 0, bC = 0;

@@ -10,10 +10,9 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info);                    // N
 // eigen-free NT scaling from b.X, b.S: W, Si, the Cholesky factors and K^(+-1/2); *converged = false: nothing usable, take
 // the SVD route
 int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged);
-// C = A B for symmetric A, B with a symmetric product (lower tiles + mirror on the direct-to-LDS path)
-int symm_prod(hipStream_t st, int n, const double* A, const double* B, double* C, double alpha = 1.0);
 // C = alpha A Bm' (n x n, column-major): the arrangement the direct-to-LDS GEMM kernel takes
-int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags = 0, double alpha = 1.0);
+int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags = 0, double alpha = 1.0,
+            double* Ct = nullptr);     // Ct: the transposed result as well
 // k largest eigenpairs (ascending), smallest eigenvalue and trace of a dense symmetric matrix
 int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
                      double* trace, int* steps_out);

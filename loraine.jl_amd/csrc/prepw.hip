@@ -230,7 +230,12 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
 // K is well conditioned along a solve (D^2 = eig(XS) stays near the central path: cond(K) <~ 1e3 where cond(X) reaches
 // 1e12), so Y = (K/c)^1/2 and Z = (K/c)^-1/2 come from the coupled Newton-Schulz iteration -- products only, on the MFMA:
 //   P = Z Y, T = a (3 I - a^2 P)/2, Y <- Y T, Z <- T Z,
-// with the one-sided scaling a = sqrt(3/(1 + l + l^2)), l <- a l (3 - a^2 l^2)/2 for spec(P)^1/2 in [l, 1]: the map never
+// taken LITERALLY: every iterate is symmetric in exact arithmetic, but the iteration is only stable as written -- with
+// any product replaced by its transposed twin (Z Y' for Z Y), or with the iterates symmetrised after each step, the
+// rounding-level commutator grows by a factor ~ cond(K)^1/2 per step once the residual is at its floor (measured on
+// thetaG11: 2e-7 -> 1e+90 in eleven steps; /tmp-free NumPy reproduction in DESIGN.md).  The direct-to-LDS GEMM computes
+// A Bm', so every product also stores its transpose (GemmDesc::C2) for the next one to read.
+// With the one-sided scaling a = sqrt(3/(1 + l + l^2)), l <- a l (3 - a^2 l^2)/2 for spec(P)^1/2 in [l, 1]: the map never
 // leaves (0, 1], so a wrong guess of l costs steps, never correctness.  c = min(||K||_1, ||K||_F) >= lambda_max(K).
 // The steps are queued without host round trips; ||I - P||_F of every step comes back in one copy.
 // tools/nt_eigenfree_proto.py emulates the whole route in NumPy against the SVD route of the oracle.
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(256) void ns_t_kernel(const double* __restrict__ P,
     s += r * r;
     T[e] = (dg ? a1 : 0.0) - a3 * p;
   }
+  if (!part) return;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -311,20 +317,16 @@ __global__ __launch_bounds__(256) void sum_sqrt_kernel(const double* __restrict_
 }
 
 // C = alpha A Bm'  (all n x n column-major): both operands contiguous along the result's dimensions -> direct-to-LDS kernel
-int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags, double alpha) {
+int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags, double alpha, double* Ct) {
   GemmDesc g;
   g.A = A; g.sAm = 1; g.sAk = n;
   g.B = Bm; g.sBk = n; g.sBn = 1;
   g.C = C; g.sCm = 1; g.sCn = n;
+  g.C2 = Ct;
   g.M = g.N = g.K = n;
   g.alpha = alpha;
   g.flags = flags;
   return gemm(st, g);
-}
-
-int symm_prod(hipStream_t st, int n, const double* A, const double* B, double* C, double alpha) {
-  // lower tiles + mirror only pays once the lower tiles alone fill the chip (n >= 3000: 300 tiles of 128)
-  return gemm_nt(st, n, A, B, C, n >= 3000 ? (GEMM_TRI_LOWER | GEMM_C_MIRROR) : 0, alpha);
 }
 
 int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
@@ -338,15 +340,22 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   size_t linv = chol_linv_doubles(n);
   const int npart = (int)std::min<size_t>(1024, (nn + 255) / 256);
   const int maxit = std::max(4, std::min(c->opt.ns_maxit, 120));
-  // scratch: P, T, Ya, Za, L_S, L_S^-1, L_S^-T (7 n^2), Linv blocks x2, chol / trsm work x2, column norms, partial sums, residuals
-  size_t need = (7 * nn + 2 * linv + 2 * ((size_t)n * CHOL_NB + (size_t)CHOL_NB * n) + 2 * (size_t)n + npart + maxit + 64) * 8;
+  // scratch: P, P', T, T', Y' Z' of the resident set, a second set Ya Ya' Za Za', L_S, L_S^-1, L_S^-T (13 n^2), Linv blocks
+  // x2, chol / trsm work x2, column norms, partial sums, residuals
+  size_t need = (13 * nn + 2 * linv + 2 * ((size_t)n * CHOL_NB + (size_t)CHOL_NB * n) + 2 * (size_t)n + npart + maxit + 64) * 8;
   LRN_TRY(ensure(c, c->scratch, need));
   double* LXt = b.LXt.as<double>();
   double* Pm = c->scratch.as<double>();
-  double* Tm = Pm + nn;
-  double* Ya = Tm + nn;
-  double* Za = Ya + nn;
-  double* LS = Za + nn;
+  double* Pt = Pm + nn;
+  double* Tm = Pt + nn;
+  double* Tt = Tm + nn;
+  double* Yt0 = Tt + nn;
+  double* Zt0 = Yt0 + nn;
+  double* Ya = Zt0 + nn;
+  double* Yta = Ya + nn;
+  double* Za = Yta + nn;
+  double* Zta = Za + nn;
+  double* LS = Zta + nn;
   double* LSi = LS + nn;
   double* LSit = LSi + nn;
   double* LinvX = LSit + nn;
@@ -400,7 +409,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   toc(c, "prepw_chol");
   tic(c);
   const dim3 tg((n + 31) / 32, (n + 31) / 32), tb(32, 8);
-  double* LSt = Za;                                  // (free until the second Newton-Schulz step, which st orders after its reader)
+  double* LSt = Zta;                                 // (free until the first Newton-Schulz step, which st orders after its reader)
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LS, n, LSt);
   if (two) LRN_HIP(c, hipEventRecord(c->evB, s2));
   hipLaunchKernelGGL(eye_kernel, dim3(ge), dim3(256), 0, s2, LSi, n);
@@ -423,24 +432,26 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   tic(c);
   // Newton-Schulz: the planned steps are the scaled ones plus the plain steps of the quadratic phase
   double ell = std::sqrt(std::min(std::max(c->opt.ns_l0, 1e-12), 0.25));
-  double* Yc = Y; double* Yn = Ya;
-  double* Zc = Z; double* Zn = Za;
+  double *Yc = Y, *Ytc = Yt0, *Zc = Z, *Ztc = Zt0;        // current set (Y, Y', Z, Z')
+  double *Yn = Ya, *Ytn = Yta, *Zn = Za, *Ztn = Zta;      // next set
+  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, Yc, n, Ytc);
   bool z_is_eye = true;
   int k = 0;
   auto one_step = [&](double a) -> int {
-    const double* Pk = Yc;
-    if (!z_is_eye) { LRN_TRY(symm_prod(st, n, Zc, Yc, Pm)); Pk = Pm; }
+    const double *Pk = Yc, *Ptk = Ytc;                    // Z = I: P = Y
+    if (!z_is_eye) { LRN_TRY(gemm_nt(st, n, Zc, Ytc, Pm, 0, 1.0, Pt)); Pk = Pm; Ptk = Pt; }
     hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Pk, n, a, Tm, part);
     hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, part, npart, res + k);
-    LRN_TRY(symm_prod(st, n, Yc, Tm, Yn));
-    std::swap(Yc, Yn);
+    hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Ptk, n, a, Tt, (double*)nullptr);
+    LRN_TRY(gemm_nt(st, n, Yc, Tt, Yn, 0, 1.0, Ytn));                                  // Y T
     if (z_is_eye) {
-      LRN_HIP(c, hipMemcpyAsync(Zc, Tm, mm, hipMemcpyDeviceToDevice, st));
+      LRN_HIP(c, hipMemcpyAsync(Zn, Tm, mm, hipMemcpyDeviceToDevice, st));
+      LRN_HIP(c, hipMemcpyAsync(Ztn, Tt, mm, hipMemcpyDeviceToDevice, st));
       z_is_eye = false;
     } else {
-      LRN_TRY(symm_prod(st, n, Tm, Zc, Zn));
-      std::swap(Zc, Zn);
+      LRN_TRY(gemm_nt(st, n, Tm, Ztc, Zn, 0, 1.0, Ztn));                               // T Z
     }
+    std::swap(Yc, Yn); std::swap(Ytc, Ytn); std::swap(Zc, Zn); std::swap(Ztc, Ztn);
     ++k;
     return LRN_OK;
   };
@@ -464,6 +475,12 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   }
   c->counts["ns_steps"] = k;
   toc(c, "prepw_ns");
+  static const bool trace = getenv("LRN_NS_TRACE") != nullptr;
+  if (trace) {
+    fprintf(stderr, "[ns n=%d] ok=%d c=%.3e res:", n, (int)ok, hres[maxit]);
+    for (int i = 0; i < k; ++i) fprintf(stderr, " %.2e", hres[i]);
+    fprintf(stderr, "\n");
+  }
   if (!ok) {
     if (two) LRN_HIP(c, hipStreamSynchronize(s2));
     c->counts["ns_fallback"] += 1;
@@ -474,10 +491,10 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   if (Yc != Y) LRN_HIP(c, hipMemcpyAsync(Y, Yc, mm, hipMemcpyDeviceToDevice, st));
   if (Zc != Z) LRN_HIP(c, hipMemcpyAsync(Z, Zc, mm, hipMemcpyDeviceToDevice, st));
   // W = L_X K^-1/2 L_X' = L_X Z L_X' / sqrt(c)                                          (prepare_W.jl:64)
-  LRN_TRY(gemm_nt(st, n, LX, Z, Pm, 0, 1.0));
+  LRN_TRY(gemm_nt(st, n, LX, Ztc, Pm, 0, 1.0));
   LRN_TRY(gemm_nt(st, n, Pm, LX, b.W.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0 / std::sqrt(b.ns_c)));
   // (K/c)^-1 = Zh^2: the sigma_mu S^-1 term of the corrector in the L_X basis
-  LRN_TRY(symm_prod(st, n, Z, Z, b.Ki.as<double>()));
+  LRN_TRY(gemm_nt(st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
   if (two) {                                                  // join: Si is complete when this returns
     LRN_HIP(c, hipEventRecord(c->evB, s2));
     LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));

@@ -16,6 +16,7 @@ def spd(n, cond, rng):
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [200, 800, 2000]
     dev = Device(0)
+    dev.set_option("profile", 1)
     for kv in filter(None, os.environ.get("LRN_OPTS", "").split(",")):
         k, v = kv.split("="); dev.set_option(k, float(v))
     rng = np.random.default_rng(7)
