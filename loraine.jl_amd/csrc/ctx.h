@@ -53,9 +53,11 @@ struct LmiBlock {
   // --- eigen-free NT scaling (prepw.hip::prepare_w_ns, option nt_mode = 1): L_X and its transpose, Yh = (K/c)^1/2,
   // Zh = (K/c)^-1/2, Ki = (K/c)^-1 for K = L_X' S L_X; per direction Bs = L_X' dS L_X, TX = L_X^-1 dX L_X^-T;
   // Qm = G RNT G' of the predictor; Lyapunov-CG work; dense copy of the rank-one factors
-  lrn::DBuf LXf, LXt, Yh, Zh, Ki, Bs, TX, Qm, lyap, Bd;
+  lrn::DBuf LXf, LXt, LSf, Yh, Zh, Ki, Bs, TX, Qm, lyap, Bd;
   double ns_c = 1.0;        // the scale c of K (host copy)
   bool nt_free = false;     // the current scaling came from prepare_w_ns: G, Gi, D, DDsi are NOT valid
+  bool chol_valid = false;  // LXf, LSf hold the Cholesky factors of the CURRENT X, S (nt_factor; lrn_ip_stats computes them as its
+                            // positive-definiteness certificate, the next prepare_w_ns re-uses them)
   bool have_Bd = false;     // dense copy of the rank-one factors (rank-one assembly from W)
 };
 

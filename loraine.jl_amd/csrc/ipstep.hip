@@ -234,6 +234,33 @@ static double tridiag_min(const std::vector<double>& a, const std::vector<double
   return 0.5 * (lo + hi);
 }
 
+// k-th smallest eigenvalue (k = 0, 1, ...) of the symmetric tridiagonal matrix by bisection on the Sturm count
+static double tridiag_kth(const std::vector<double>& a, const std::vector<double>& b, int m, int k) {
+  double lo = a[0], hi = a[0];
+  for (int i = 0; i < m; ++i) {
+    double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < m - 1 ? std::fabs(b[i]) : 0.0);
+    lo = std::min(lo, a[i] - r);
+    hi = std::max(hi, a[i] + r);
+  }
+  auto count_below = [&](double x) {
+    int cnt = 0;
+    double d = 1.0;
+    for (int i = 0; i < m; ++i) {
+      double bb = i > 0 ? b[i - 1] * b[i - 1] : 0.0;
+      d = a[i] - x - (i > 0 ? bb / d : 0.0);
+      if (d == 0.0) d = -1e-300;
+      if (d < 0.0) ++cnt;
+    }
+    return cnt;
+  };
+  for (int it = 0; it < 200; ++it) {
+    double mid = 0.5 * (lo + hi);
+    if (mid == lo || mid == hi) break;
+    if (count_below(mid) >= k + 1) hi = mid; else lo = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
 // |beta_m * s_m| for the Ritz pair (theta, s) of T_m: the residual norm ||M v - theta v|| of the
 // Ritz vector, a rigorous bound on the distance from theta to the spectrum.  s by two steps of
 // inverse iteration on the tridiagonal matrix (Thomas algorithm with a tiny shift).
@@ -332,6 +359,19 @@ static int lz_collect(lrn_ctx* c, LzRun& r) {
   // upper bound of lambda_min) the callers only need the sign class once theta has settled
   const double res = ritz_residual(r.a, r.b, mm_, r.theta);
   if (res <= 1e-11 * std::max(std::fabs(r.theta), 1e-4 * r.scale)) { r.conv = true; r.done = true; return LRN_OK; }
+  // Kato-Temple: theta - lambda_min <= res^2 / (lambda_2 - theta).  lambda_2 is bounded below through the second Ritz
+  // pair (an eigenvalue lies within res2 of theta2; if that eigenvalue is lambda_min itself -- a ghost copy -- the gap
+  // below is <= 0 and the rule does not fire).  The step-length rule consumes lambda_min to ~1e-10 relative.
+  static const double kt_tol = getenv("LRN_EIGMIN_KT") ? atof(getenv("LRN_EIGMIN_KT")) : 1e-10;
+  if (kt_tol > 0.0 && mm_ >= 8 && r.theta <= -1e-6 && res <= 1e-3 * std::max(std::fabs(r.theta), 1e-4 * r.scale)) {
+    const double th2 = tridiag_kth(r.a, r.b, mm_, 1);
+    const double res2 = ritz_residual(r.a, r.b, mm_, th2);
+    const double gap = (th2 - res2) - r.theta;
+    if (gap > 0.0 && res < 0.25 * gap && res * res / gap <= kt_tol * std::fabs(r.theta)) {
+      r.conv = true; r.done = true;
+      return LRN_OK;
+    }
+  }
   if (r.have_prev && r.theta > 0.0 && std::fabs(r.theta - r.theta_prev) <= 1e-3 * r.theta && r.m >= 64) { r.done = true; return LRN_OK; }
   r.theta_prev = r.theta;
   r.have_prev = true;
@@ -356,6 +396,8 @@ int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, 
     LRN_TRY(lz_collect(c, r));
   }
   *lam = r.theta;
+  c->counts["lanczos_steps"] += r.m;
+  c->counts["lanczos_runs"] += 1;
   if (steps_out) *steps_out = r.m;
   if (converged) *converged = r.conv;
   if (scale_out) *scale_out = r.scale;
@@ -384,7 +426,11 @@ static int eigmin_dev_pair(lrn_ctx* c, const double* M1, const double* M2, int n
       if (!r[k].done) lz_launch(r[k]);
     }
   }
-  for (int k = 0; k < 2; ++k) { lam[k] = r[k].theta; conv[k] = r[k].conv; scale[k] = r[k].scale; }
+  for (int k = 0; k < 2; ++k) {
+    lam[k] = r[k].theta; conv[k] = r[k].conv; scale[k] = r[k].scale;
+    c->counts["lanczos_steps"] += r[k].m;
+    c->counts["lanczos_runs"] += 1;
+  }
   LRN_HIP(c, hipGetLastError());
   return LRN_OK;
 }
@@ -639,6 +685,7 @@ extern "C" int lrn_ip_set_iterate(lrn_ctx* c, int il, const double* X, const dou
   LRN_TRY(copy_in(c, b.S.p, S, mm_));
   LRN_HIP(c, hipMemsetAsync(b.RNT.p, 0, mm_, c->stream));
   b.have_Vprev = false;
+  b.chol_valid = false;
   return LRN_OK;
 }
 
@@ -652,6 +699,7 @@ extern "C" int lrn_ip_get_iterate(lrn_ctx* c, int il, double* X, double* S) {
 extern "C" int lrn_ip_add_diag(lrn_ctx* c, int il, int which, double eps) {
   BLK(il);
   if (which != 1 && which != 2) return LRN_ERR_ARG;
+  b.chol_valid = false;
   hipLaunchKernelGGL(add_diag_mat_kernel, dim3((b.msz + 255) / 256), dim3(256), 0, c->stream,
                      (which == 1 ? b.X : b.S).as<double>(), b.msz, eps);
   return LRN_OK;
@@ -877,6 +925,7 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
       LRN_TRY(mm(c, m, t1, false, b.G.as<double>(), false, t2));
       hipLaunchKernelGGL(rnt_kernel, dim3(g), dim3(256), 0, c->stream, t2, b.D.as<double>(), b.RNT.as<double>(), m);
     } else {
+      b.chol_valid = false;
       hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, b.X.as<double>(), alpha[0],
                          b.delX.as<double>(), 0.0, (const double*)nullptr, mm_);
       hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.X.as<double>(), m);
@@ -907,7 +956,17 @@ extern "C" int lrn_ip_stats(lrn_ctx* c, double* out5) {
   for (int il = 0; il < c->nlmi; ++il) {
     LmiBlock& b = c->lmi[il];
     double lx = 0, ls = 0;
-    LRN_TRY(eigmin_certified_pair(c, b.X.as<double>(), b.S.as<double>(), b.msz, &lx, &ls));
+    bool have = false;
+    if (c->opt.nt_mode == 1 && b.msz > 1) {
+      // the callers consume max(0, -eigmin) (Solvers.jl:503-511): a successful Cholesky factorisation IS the certificate
+      // that both terms vanish, and the next prepare_W starts with exactly these two factorisations -- they are kept
+      // (b.chol_valid).  Reported then: the smallest pivots (positive upper bounds of the smallest eigenvalues).
+      int info = 0;
+      double piv[2] = {0.0, 0.0};
+      LRN_TRY(nt_factor(c, b, &info, piv));
+      if (info == 0) { lx = piv[0]; ls = piv[1]; have = true; c->counts["stats_chol"] += 1; }
+    }
+    if (!have) LRN_TRY(eigmin_certified_pair(c, b.X.as<double>(), b.S.as<double>(), b.msz, &lx, &ls));
     out5[5 * il + 1] = lx;
     out5[5 * il + 2] = ls;
     out5[5 * il + 3] = std::sqrt(out5[5 * il + 3]);

@@ -161,7 +161,7 @@ using namespace lrn;
 static void free_block(LmiBlock& b) {
   for (DBuf* d : {&b.ent_ptr, &b.ent_r, &b.ent_c, &b.ent_v, &b.Adense, &b.hidx, &b.sigma_d, &b.ipos_d, &b.cq_q, &b.cq_ptr, &b.cq_j, &b.cq_v, &b.pc_ptr, &b.pc_r, &b.pc_t, &b.ent_t, &b.Mv, &b.Zs, &b.b_ptr, &b.b_col,
                   &b.b_val, &b.X, &b.S, &b.W, &b.G, &b.Gi, &b.Si, &b.D, &b.DDsi, &b.Vprev, &b.Cd, &b.Rd, &b.delX, &b.delS, &b.Xn, &b.Sn, &b.RNT,
-                  &b.t0, &b.t1, &b.t2, &b.LXf, &b.LXt, &b.Yh, &b.Zh, &b.Ki, &b.Bs, &b.TX, &b.Qm, &b.lyap, &b.Bd})
+                  &b.t0, &b.t1, &b.t2, &b.LXf, &b.LXt, &b.LSf, &b.Yh, &b.Zh, &b.Ki, &b.Bs, &b.TX, &b.Qm, &b.lyap, &b.Bd})
     release(*d);
 }
 

@@ -10,6 +10,9 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info);                    // N
 // eigen-free NT scaling from b.X, b.S: W, Si, the Cholesky factors and K^(+-1/2); *converged = false: nothing usable, take
 // the SVD route
 int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged);
+// Cholesky factors of b.X, b.S into b.LXf, b.LSf (two streams); info = 0, 1 (X not PD), 2 (S not PD) as prepare_W.jl:33-34;
+// minpiv[2] (may be null): smallest pivots L_ii^2 (upper bounds of the smallest eigenvalues).  Sets b.chol_valid.
+int nt_factor(lrn_ctx* c, LmiBlock& b, int* info, double* minpiv);
 // C = alpha A Bm' (n x n, column-major): the arrangement the direct-to-LDS GEMM kernel takes
 int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags = 0, double alpha = 1.0,
             double* Ct = nullptr);     // Ct: the transposed result as well

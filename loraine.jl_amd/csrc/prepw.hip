@@ -329,6 +329,79 @@ int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C,
   return gemm(st, g);
 }
 
+// smallest pivot of a Cholesky factor: out = min_i L_ii^2
+__global__ __launch_bounds__(256) void min_pivot_kernel(const double* __restrict__ L, int n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double m = 1e300;
+  for (int i = threadIdx.x; i < n; i += 256) { const double v = L[(long)i * n + i]; m = fmin(m, v * v); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+}
+
+int nt_factor(lrn_ctx* c, LmiBlock& b, int* info, double* minpiv) {
+  const int n = b.msz;
+  const size_t nn = (size_t)n * n, mm = nn * 8;
+  hipStream_t st = c->stream;
+  *info = 0;
+  b.chol_valid = false;
+  LRN_TRY(ensure(c, b.LXf, mm));
+  LRN_TRY(ensure(c, b.LSf, mm));
+  const size_t linv = chol_linv_doubles(n);
+  LRN_TRY(ensure(c, c->lxbuf, (2 * linv + 2 * (size_t)n * CHOL_NB + 16) * 8));
+  double* LinvX = c->lxbuf.as<double>();
+  double* LinvS = LinvX + linv;
+  double* cw = LinvS + linv;
+  double* cw2 = cw + (size_t)n * CHOL_NB;
+  double* piv = cw2 + (size_t)n * CHOL_NB;
+  LRN_TRY(ensure(c, c->info_dev, 64));
+  int* dinfo = c->info_dev.as<int>();
+  int* dinfoS = dinfo + 12;
+  if (!c->stream2) LRN_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  if (!c->evA) {
+    LRN_HIP(c, hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
+    LRN_HIP(c, hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
+  }
+  hipStream_t s2 = c->opt.prepw_streams ? c->stream2 : st;
+  const bool two = s2 != st;
+  const unsigned ge = nb2((long)nn);
+  double *LX = b.LXf.as<double>(), *LS = b.LSf.as<double>();
+  if (two) {
+    LRN_HIP(c, hipEventRecord(c->evA, st));
+    LRN_HIP(c, hipStreamWaitEvent(s2, c->evA, 0));
+  }
+  tic(c);
+  LRN_HIP(c, hipMemcpyAsync(LX, b.X.p, mm, hipMemcpyDeviceToDevice, st));
+  LRN_HIP(c, hipMemsetAsync(dinfo, 0, 4, st));
+  LRN_TRY(potrf_lower(st, LX, n, n, LinvX, cw, dinfo));
+  hipLaunchKernelGGL(tril_kernel, dim3(ge), dim3(256), 0, st, LX, n);
+  hipLaunchKernelGGL(min_pivot_kernel, dim3(1), dim3(256), 0, st, LX, n, piv);
+  LRN_HIP(c, hipMemcpyAsync(LS, b.S.p, mm, hipMemcpyDeviceToDevice, s2));
+  LRN_HIP(c, hipMemsetAsync(dinfoS, 0, 4, s2));
+  LRN_TRY(potrf_lower(s2, LS, n, n, LinvS, two ? cw2 : cw, dinfoS));
+  hipLaunchKernelGGL(tril_kernel, dim3(ge), dim3(256), 0, s2, LS, n);
+  hipLaunchKernelGGL(min_pivot_kernel, dim3(1), dim3(256), 0, s2, LS, n, piv + 1);
+  // the verdicts, in the reference's order (prepare_W.jl:33-34)
+  int h[2] = {0, 0};
+  double hp[2] = {0.0, 0.0};
+  LRN_HIP(c, hipMemcpyAsync(&h[0], dinfo, 4, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipMemcpyAsync(&hp[0], piv, 8, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipMemcpyAsync(&h[1], dinfoS, 4, hipMemcpyDeviceToHost, s2));
+  LRN_HIP(c, hipMemcpyAsync(&hp[1], piv + 1, 8, hipMemcpyDeviceToHost, s2));
+  LRN_HIP(c, hipStreamSynchronize(st));
+  if (two) LRN_HIP(c, hipStreamSynchronize(s2));
+  toc(c, "prepw_chol");
+  if (h[0] != 0 || h[1] != 0) {
+    *info = h[0] != 0 ? 1 : 2;
+    return LRN_OK;
+  }
+  if (minpiv) { minpiv[0] = hp[0]; minpiv[1] = hp[1]; }
+  b.chol_valid = true;
+  return LRN_OK;
+}
+
 int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   const int n = b.msz;
   const size_t nn = (size_t)n * n, mm = nn * 8;
@@ -336,13 +409,17 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   *info = 0;
   *converged = false;
   b.nt_free = false;
-  for (DBuf* d : {&b.LXf, &b.LXt, &b.Yh, &b.Zh, &b.Ki, &b.Bs, &b.TX, &b.Qm}) LRN_TRY(ensure(c, *d, mm));
-  size_t linv = chol_linv_doubles(n);
+  if (!b.chol_valid) {
+    LRN_TRY(nt_factor(c, b, info, nullptr));
+    if (*info != 0) return LRN_OK;
+  }
+  b.chol_valid = false;            // (consumed: whoever changes X, S afterwards need not remember to reset it)
+  for (DBuf* d : {&b.LXt, &b.Yh, &b.Zh, &b.Ki, &b.Bs, &b.TX, &b.Qm}) LRN_TRY(ensure(c, *d, mm));
   const int npart = (int)std::min<size_t>(1024, (nn + 255) / 256);
   const int maxit = std::max(4, std::min(c->opt.ns_maxit, 120));
-  // scratch: P, P', T, T', Y' Z' of the resident set, a second set Ya Ya' Za Za', L_S, L_S^-1, L_S^-T (13 n^2), Linv blocks
-  // x2, chol / trsm work x2, column norms, partial sums, residuals
-  size_t need = (13 * nn + 2 * linv + 2 * ((size_t)n * CHOL_NB + (size_t)CHOL_NB * n) + 2 * (size_t)n + npart + maxit + 64) * 8;
+  // scratch: P, P', T, T', Y' Z' of the resident set, a second set Ya Ya' Za Za', L_S^-1, L_S^-T (12 n^2), trsm work,
+  // column norms, partial sums, residuals
+  size_t need = (12 * nn + (size_t)CHOL_NB * n + 2 * (size_t)n + npart + maxit + 64) * 8;
   LRN_TRY(ensure(c, c->scratch, need));
   double* LXt = b.LXt.as<double>();
   double* Pm = c->scratch.as<double>();
@@ -355,29 +432,15 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   double* Yta = Ya + nn;
   double* Za = Yta + nn;
   double* Zta = Za + nn;
-  double* LS = Zta + nn;
-  double* LSi = LS + nn;
+  double* LSi = Zta + nn;
   double* LSit = LSi + nn;
-  double* LinvX = LSit + nn;
-  double* LinvS = LinvX + linv;
-  double* cw = LinvS + linv;
-  double* tw = cw + (size_t)n * CHOL_NB;
-  double* cw2 = tw + (size_t)CHOL_NB * n;
-  double* tw2 = cw2 + (size_t)n * CHOL_NB;
+  double* tw2 = LSit + nn;
   double* colsum = tw2 + (size_t)CHOL_NB * n;
   double* colsq = colsum + n;
   double* part = colsq + n;
   double* res = part + npart;        // res[0..maxit), then sc[0..1]
   double* sc = res + maxit;
-  double* LX = b.LXf.as<double>();
-  LRN_TRY(ensure(c, c->info_dev, 64));
-  int* dinfo = c->info_dev.as<int>();
-  int* dinfoS = dinfo + 12;
-  if (!c->stream2) LRN_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  if (!c->evA) {
-    LRN_HIP(c, hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
-    LRN_HIP(c, hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
-  }
+  double *LX = b.LXf.as<double>(), *LS = b.LSf.as<double>();
   hipStream_t s2 = c->opt.prepw_streams ? c->stream2 : st;
   const bool two = s2 != st;
   const unsigned ge = nb2((long)nn);
@@ -386,34 +449,12 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
     LRN_HIP(c, hipStreamWaitEvent(s2, c->evA, 0));
   }
   tic(c);
-  // X side: L_X, its transpose, its inverse
-  LRN_HIP(c, hipMemcpyAsync(LX, b.X.p, mm, hipMemcpyDeviceToDevice, st));
-  LRN_HIP(c, hipMemsetAsync(dinfo, 0, 4, st));
-  LRN_TRY(potrf_lower(st, LX, n, n, LinvX, cw, dinfo));
-  hipLaunchKernelGGL(tril_kernel, dim3(ge), dim3(256), 0, st, LX, n);
-  // S side (second stream): L_S, its inverse, Si = L_S^-T L_S^-1                       (prepare_W.jl:34,68)
-  LRN_HIP(c, hipMemcpyAsync(LS, b.S.p, mm, hipMemcpyDeviceToDevice, s2));
-  LRN_HIP(c, hipMemsetAsync(dinfoS, 0, 4, s2));
-  LRN_TRY(potrf_lower(s2, LS, n, n, LinvS, two ? cw2 : cw, dinfoS));
-  hipLaunchKernelGGL(tril_kernel, dim3(ge), dim3(256), 0, s2, LS, n);
-  // the verdicts first, in the reference's order (prepare_W.jl:33-34): nothing else is queued on a failed factor
-  int h[2] = {0, 0};
-  LRN_HIP(c, hipMemcpyAsync(&h[0], dinfo, 4, hipMemcpyDeviceToHost, st));
-  LRN_HIP(c, hipMemcpyAsync(&h[1], dinfoS, 4, hipMemcpyDeviceToHost, s2));
-  LRN_HIP(c, hipStreamSynchronize(st));
-  if (two) LRN_HIP(c, hipStreamSynchronize(s2));
-  if (h[0] != 0 || h[1] != 0) {
-    *info = h[0] != 0 ? 1 : 2;
-    return LRN_OK;
-  }
-  toc(c, "prepw_chol");
-  tic(c);
   const dim3 tg((n + 31) / 32, (n + 31) / 32), tb(32, 8);
   double* LSt = Zta;                                 // (free until the first Newton-Schulz step, which st orders after its reader)
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LS, n, LSt);
   if (two) LRN_HIP(c, hipEventRecord(c->evB, s2));
   hipLaunchKernelGGL(eye_kernel, dim3(ge), dim3(256), 0, s2, LSi, n);
-  LRN_TRY(trsm_left_lower(s2, LS, n, n, LinvS, false, LSi, n, n, two ? tw2 : tw));
+  LRN_TRY(trsm_left_lower(s2, LS, n, n, nullptr, false, LSi, n, n, tw2));
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LSi, n, LSit);   // L_S^-T
   LRN_TRY(gemm_nt(s2, n, LSit, LSit, b.Si.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0));
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, LX, n, LXt);

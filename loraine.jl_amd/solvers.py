@@ -480,6 +480,8 @@ class MySolver:
                 svd_sweeps=d.count("svd_sweeps"), find_step_ms=d.timing("find_step"),
                 ns_steps=d.count("ns_steps"), lyap_steps=d.count("lyap_steps"), lyap_ms=d.timing("lyap"),
                 ns_fallback=d.count("ns_fallback"), lyap_fallback=d.count("lyap_fallback"),
+                lanczos_steps=d.count("lanczos_steps"), lanczos_runs=d.count("lanczos_runs"),
+                stats_chol=d.count("stats_chol"), eigmin_chol_tests=d.count("eigmin_chol_tests"),
                 schur_chol=d.count("schur_chol"), schur_via_l=d.count("schur_via_l"), wchol_fail=d.count("wchol_fail"),
                 alpha=[float(a) for a in self.alpha] + [float(self.alpha_lin)],
                 beta=[float(b) for b in self.beta] + [float(self.beta_lin)], regcount=self.regcount,

@@ -27,6 +27,8 @@ for name in sys.argv[1:]:
         b = tr[1][i] if i < len(tr[1]) else None
         s = "%3d " % (i + 1)
         if a: s += " svd: %.10e %.2e a=%s b=%s |" % (a["primal_obj"], a["dimacs"], np.round(a["alpha"], 4), np.round(a["beta"], 4))
+        if a: s += " lz %d/%d fs %.2f |" % (a["lanczos_steps"], a["lanczos_runs"], a["find_step_ms"])
+        if b: s += " lz %d/%d ct %d fs %.2f it %.2f" % (b["lanczos_steps"], b["lanczos_runs"], b["eigmin_chol_tests"], b["find_step_ms"], b["itertime"] * 1e3)
         if b: s += " ns: %.10e %.2e a=%s b=%s ns %d lyap %d fb %d/%d pw %.2f ly %.2f" % (
             b["primal_obj"], b["dimacs"], np.round(b["alpha"], 4), np.round(b["beta"], 4), b["ns_steps"], b["lyap_steps"],
             b["ns_fallback"], b["lyap_fallback"], b["gpu_ms"]["prepare_w"], b["lyap_ms"])
