@@ -63,6 +63,7 @@ int lrn_destroy(lrn_ctx* c) {
   if (c->evB) (void)hipEventDestroy(c->evB);
   (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
   delete c;
   return LRN_OK;
 }
@@ -103,6 +104,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "nt_mode")) c->opt.nt_mode = (int)value;
   else if (!strcmp(key, "ns_l0")) c->opt.ns_l0 = value;
   else if (!strcmp(key, "ns_maxit")) c->opt.ns_maxit = (int)value;
+  else if (!strcmp(key, "ns_dual")) c->opt.ns_dual = (int)value;
   else if (!strcmp(key, "lyap_tol")) c->opt.lyap_tol = value;
   else if (!strcmp(key, "lyap_maxit")) c->opt.lyap_maxit = (int)value;
   else if (!strcmp(key, "shard_bs")) { if (value < 0) return LRN_ERR_ARG; c->shard_bs_opt = (int)value; lrn::update_shard_bs(c); }

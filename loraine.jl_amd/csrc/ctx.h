@@ -91,7 +91,8 @@ struct LrnOptions {
   bool jacobi_warm = true;
   int nt_mode = 1;                // lrn_ip_prepare_w: 1 = eigen-free NT scaling (Newton-Schulz square roots of K = L_X'SL_X, Lyapunov
                                   // solve for the second-order term; falls back to the SVD when it does not converge), 0 = SVD always
-  double ns_l0 = 1e-3;            // Newton-Schulz schedule: assumed lower end of spec(K)/c (slower, never wrong, when cond(K) is larger)
+  double ns_l0 = 2e-3;            // Newton-Schulz schedule: assumed lower end of spec(K)/c (slower, never wrong, when cond(K) is larger)
+  int ns_dual = -1;               // Newton-Schulz: transposed twins from the GEMM epilogue (1), a transpose pass (0), auto (-1)
   int ns_maxit = 40;              // Newton-Schulz steps before the SVD fallback
   double lyap_tol = 1e-12;        // relative residual of the Lyapunov CG (second-order term of the corrector)
   int lyap_maxit = 300;
@@ -144,6 +145,8 @@ struct lrn_ctx {
   bool profile = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr;      // stream <-> stream2 dependencies (prepare_w_block)
+  hipStream_t stream3 = nullptr;                // Newton-Schulz: the T Z product beside Y T (prepare_w_ns)
+  hipEvent_t evC = nullptr, evD = nullptr;
   // generic scratch
   lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lzbuf2, lxbuf, ezbuf;
   // preconditioner / CG state

@@ -207,6 +207,85 @@ __global__ __launch_bounds__(1024) void lz_step_kernel(const double* __restrict_
   if (t == 0) { ab[2 * j] = a; ab[2 * j + 1] = b; }
 }
 
+// One Lanczos step in ONE launch (n <= LZ_FUSED_MAX; round 3).  The two-kernel step above costs two dependent launches
+// (10 + 7 us at msz 800, rocprofv3) for a few microseconds of work.  Here every workgroup first finishes step j-1 by
+// itself -- alpha_{j-1} from the partial dots of the previous launch, w = y_{j-1} - alpha q_{j-1} - beta_{j-2} q_{j-2},
+// beta_{j-1} = ||w|| and q_j = w / beta_{j-1} for ALL n entries, redundantly (n <= 4096 flops per thread block, in LDS) --
+// and then computes its 16 rows of y_j = M q_j and their share of q_j . y_j.  Vectors rotate through three (q) and two (y)
+// buffers so that nothing a workgroup still reads is overwritten inside a launch.  `do_symv` = 0: only finish step j-1
+// (last launch of a batch: the host needs alpha, beta of every step it reads).
+static constexpr int LZ_FUSED_MAX = 4096;
+__global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict__ M, int n, int nwg, int j, int do_symv,
+                                                       double* __restrict__ Q3, double* __restrict__ Y2, double* __restrict__ PA2,
+                                                       double* __restrict__ ab) {
+  extern __shared__ double qs[];            // q_j (n doubles)
+  __shared__ double sh[16 * 16 + 8];
+  const int t = threadIdx.x;
+  double* qj = Q3 + (size_t)(j % 3) * n;
+  if (j == 0) {
+    for (int i = t; i < n; i += 256) qs[i] = qj[i];
+  } else {
+    const double* qm1 = Q3 + (size_t)((j + 2) % 3) * n;     // q_{j-1}
+    const double* qm2 = Q3 + (size_t)((j + 1) % 3) * n;     // q_{j-2}
+    const double* ym1 = Y2 + (size_t)((j + 1) & 1) * n;     // y_{j-1}
+    const double* pa = PA2 + (size_t)((j + 1) & 1) * nwg;
+    double a = 0.0;
+    for (int e = t; e < nwg; e += 256) a += pa[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((t & 63) == 0) sh[t >> 6] = a;
+    __syncthreads();
+    const double alpha = sh[0] + sh[1] + sh[2] + sh[3];
+    const double bprev = j > 1 ? ab[2 * (j - 2) + 1] : 0.0;
+    __syncthreads();
+    double b2 = 0.0;
+    for (int i = t; i < n; i += 256) {
+      const double v = ym1[i] - alpha * qm1[i] - (j > 1 ? bprev * qm2[i] : 0.0);
+      qs[i] = v;
+      b2 += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) b2 += __shfl_down(b2, off, 64);
+    if ((t & 63) == 0) sh[t >> 6] = b2;
+    __syncthreads();
+    const double beta = sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
+    const double r = beta > 0.0 ? 1.0 / beta : 0.0;
+    for (int i = t; i < n; i += 256) {
+      const double v = qs[i] * r;
+      qs[i] = v;
+      if (blockIdx.x == 0) qj[i] = v;
+    }
+    if (blockIdx.x == 0 && t == 0) { ab[2 * (j - 1)] = alpha; ab[2 * (j - 1) + 1] = beta; }
+  }
+  __syncthreads();
+  if (!do_symv) return;
+  // rows [16 blockIdx.x, +16): thread (r, g) sums the columns g, g + 16, ...
+  const int r = t & 15, g = t >> 4;
+  const int i = blockIdx.x * 16 + r;
+  double acc = 0.0;
+  if (i < n) {
+    const double* mrow = M + i;
+#pragma unroll 4
+    for (int col = g; col < n; col += 16) acc += mrow[(size_t)col * n] * qs[col];
+  }
+  sh[g * 16 + r] = acc;
+  __syncthreads();
+  if (t < 16) {
+    double y = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) y += sh[gg * 16 + t];
+    const int ii = blockIdx.x * 16 + t;
+    double d = 0.0;
+    if (ii < n) {
+      Y2[(size_t)(j & 1) * n + ii] = y;
+      d = qs[ii] * y;
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) d += __shfl_down(d, off, 16);
+    if (t == 0) PA2[(size_t)(j & 1) * nwg + blockIdx.x] = d;
+  }
+}
+
 // smallest eigenvalue of the symmetric tridiagonal (a_0..a_{m-1}; b_0..b_{m-2}) by bisection
 static double tridiag_min(const std::vector<double>& a, const std::vector<double>& b, int m) {
   double lo = a[0], hi = a[0];
@@ -305,6 +384,8 @@ struct LzRun {
   std::vector<double> a, b, hab;
   double theta = 0.0, theta_prev = 0.0, scale = 0.0;
   bool have_prev = false, conv = false, done = false;
+  bool fused = false;                       // lz_fused_kernel: Q3 = q (3 n), Y2 = w (2 n), PA2 = ypart (2 nwg)
+  int nwg = 0;
 };
 
 static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st, DBuf& buf) {
@@ -315,12 +396,15 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   r.nchunk = std::max(1, std::min(64, n / 64));
   r.cper = (n + r.nchunk - 1) / r.nchunk;
   r.nchunk = (n + r.cper - 1) / r.cper;
-  LRN_TRY(ensure(c, buf, ((size_t)3 * n + (size_t)r.nchunk * n + 2 * (size_t)r.mmax + 64) * 8));
-  r.q = buf.as<double>();
+  static const bool no_fused = getenv("LRN_LZ_UNFUSED") != nullptr;
+  r.fused = !no_fused && n <= LZ_FUSED_MAX && n >= 32;
+  r.nwg = (n + 15) / 16;
+  LRN_TRY(ensure(c, buf, ((size_t)5 * n + (size_t)std::max(r.nchunk * n, 2 * r.nwg) + 2 * (size_t)r.mmax + 64) * 8));
+  r.q = buf.as<double>();                 // fused: Q3 = q[0..3n)
   r.qprev = r.q + n;
-  r.w = r.qprev + n;
-  r.ypart = r.w + n;
-  r.ab = r.ypart + (size_t)r.nchunk * n;
+  r.w = r.q + 3 * (size_t)n;              // fused: Y2 = w[0..2n)
+  r.ypart = r.w + 2 * (size_t)n;          // fused: PA2
+  r.ab = r.ypart + (size_t)std::max(r.nchunk * n, 2 * r.nwg);
   return LRN_OK;
 }
 
@@ -333,6 +417,13 @@ static void lz_start(LzRun& r) {
 static void lz_launch(LzRun& r) {
   const int batch = r.n <= 16 ? r.n : 16;
   r.m1 = std::min(r.mmax, r.m + batch);
+  if (r.fused) {
+    const size_t lds = (size_t)r.n * 8;
+    for (int j = r.m; j < r.m1; ++j)
+      hipLaunchKernelGGL(lz_fused_kernel, dim3(r.nwg), dim3(256), lds, r.st, r.M, r.n, r.nwg, j, 1, r.q, r.w, r.ypart, r.ab);
+    hipLaunchKernelGGL(lz_fused_kernel, dim3(1), dim3(256), lds, r.st, r.M, r.n, r.nwg, r.m1, 0, r.q, r.w, r.ypart, r.ab);
+    return;
+  }
   for (int j = r.m; j < r.m1; ++j) {
     hipLaunchKernelGGL(symv_part_kernel, dim3((r.n + 255) / 256, r.nchunk), dim3(256), 0, r.st, r.M, r.n, r.cper, r.q, r.ypart);
     hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, r.st, r.ypart, r.nchunk, r.n, j, r.q, r.qprev, r.w, r.ab);
@@ -832,7 +923,7 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
       hipLaunchKernelGGL(tx_kernel, dim3(g), dim3(256), 0, c->stream, t3, sigma_mu / b.ns_c, b.Ki.as<double>(),
                          predict ? (const double*)nullptr : b.RNT.as<double>(), b.TX.as<double>(), m);
       LRN_TRY(gemm_nt(c->stream, m, b.LXf.as<double>(), b.TX.as<double>(), t0));
-      LRN_TRY(gemm_nt(c->stream, m, t0, b.LXf.as<double>(), b.delX.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR));
+      LRN_TRY(gemm_nt_sym(c->stream, m, t0, b.LXf.as<double>(), b.delX.as<double>(), 1.0));
       // the scaled directions of the step-length rule are orthogonally similar to TX and T               (:263-285)
       LRN_TRY(eigmin_certified_pair(c, b.TX.as<double>(), t3, m, &lamX, &lamS));
       alpha[il] = lamX > -1e-6 ? 0.99 : std::min(1.0, -tau / lamX);
@@ -907,7 +998,7 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
         c->counts["lyap_solves"] += 1;
         if (ok) {
           LRN_TRY(gemm_nt(c->stream, m, b.LXf.as<double>(), b.RNT.as<double>(), t0));
-          LRN_TRY(gemm_nt(c->stream, m, t0, b.LXf.as<double>(), b.Qm.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR));
+          LRN_TRY(gemm_nt_sym(c->stream, m, t0, b.LXf.as<double>(), b.Qm.as<double>(), 1.0));
           toc(c, "lyap");
           continue;
         }

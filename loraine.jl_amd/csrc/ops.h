@@ -16,6 +16,8 @@ int nt_factor(lrn_ctx* c, LmiBlock& b, int* info, double* minpiv);
 // C = alpha A Bm' (n x n, column-major): the arrangement the direct-to-LDS GEMM kernel takes
 int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags = 0, double alpha = 1.0,
             double* Ct = nullptr);     // Ct: the transposed result as well
+// the same for a product that is symmetric in exact arithmetic; C comes back exactly symmetric
+int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha = 1.0);
 // k largest eigenpairs (ascending), smallest eigenvalue and trace of a dense symmetric matrix
 int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
                      double* trace, int* steps_out);

@@ -329,6 +329,30 @@ int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C,
   return gemm(st, g);
 }
 
+// (M + M')/2 in place
+__global__ void sym_inplace_kernel(double* __restrict__ M, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    if (i < j) {
+      const long f = (long)j + (long)i * n;
+      const double v = 0.5 * (M[e] + M[f]);
+      M[e] = v;
+      M[f] = v;
+    }
+  }
+}
+
+// C = alpha A Bm' for a product that is symmetric in exact arithmetic, returned exactly symmetric: lower tiles + mirror on
+// the 128-tile direct-to-LDS kernel where that fills the chip, the plain product and a symmetrising pass below (at msz 800
+// the 28 lower tiles of 128 take 121 us, the full product on 64-tiles 35 us)
+int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha) {
+  if (n >= 1500) return gemm_nt(st, n, A, Bm, C, GEMM_TRI_LOWER | GEMM_C_MIRROR, alpha);
+  LRN_TRY(gemm_nt(st, n, A, Bm, C, 0, alpha));
+  hipLaunchKernelGGL(sym_inplace_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, C, n);
+  return LRN_OK;
+}
+
 // smallest pivot of a Cholesky factor: out = min_i L_ii^2
 __global__ __launch_bounds__(256) void min_pivot_kernel(const double* __restrict__ L, int n, double* __restrict__ out) {
   __shared__ double sh[4];
@@ -456,7 +480,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   hipLaunchKernelGGL(eye_kernel, dim3(ge), dim3(256), 0, s2, LSi, n);
   LRN_TRY(trsm_left_lower(s2, LS, n, n, nullptr, false, LSi, n, n, tw2));
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LSi, n, LSit);   // L_S^-T
-  LRN_TRY(gemm_nt(s2, n, LSit, LSit, b.Si.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0));
+  LRN_TRY(gemm_nt_sym(s2, n, LSit, LSit, b.Si.as<double>(), 1.0));
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, LX, n, LXt);
   // K = CC' CC with CC = L_S' L_X (prepare_W.jl:39) -- NOT L_X' S L_X: with cond(X), cond(S) at 1e10 the entries of
   // |L_X'| |S| |L_X| are 1e10 times those of K and the explicit product has no correct digit left (measured: the
@@ -465,7 +489,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   double* Z = b.Zh.as<double>();
   if (two) LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
   LRN_TRY(gemm_nt(st, n, LXt, LSt, Pm, 0, 1.0));                                      // CC' = L_X' L_S
-  LRN_TRY(gemm_nt(st, n, Pm, Pm, Tm, GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0));           // K = CC' CC
+  LRN_TRY(gemm_nt_sym(st, n, Pm, Pm, Tm, 1.0));                                        // K = CC' CC
   hipLaunchKernelGGL(colnorm_kernel, dim3(n), dim3(256), 0, st, Tm, n, colsum, colsq);
   hipLaunchKernelGGL(normc_kernel, dim3(1), dim3(256), 0, st, colsum, colsq, n, sc);
   hipLaunchKernelGGL(scale_dev_kernel, dim3(ge), dim3(256), 0, st, Tm, sc, (long)nn, Y);
@@ -478,30 +502,59 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, Yc, n, Ytc);
   bool z_is_eye = true;
   int k = 0;
+  // the transposed twin of a product: stored by the GEMM epilogue (8-byte scattered stores: 61 against 35 us at msz 800 on
+  // the 64-tile kernel) or by a transpose pass of its own (8 us there)
+  const bool dual = c->opt.ns_dual == 1 || (c->opt.ns_dual < 0 && n >= 1500);
+  auto prod = [&](hipStream_t sx, const double* A, const double* Bm, double* C, double* Ct) -> int {
+    if (dual) return gemm_nt(sx, n, A, Bm, C, 0, 1.0, Ct);
+    LRN_TRY(gemm_nt(sx, n, A, Bm, C, 0, 1.0));
+    hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, sx, C, n, Ct);
+    return LRN_OK;
+  };
+  // Y T and T Z are independent: the second one on a third stream, so that two workgroups share every CU where one
+  // product alone (256 tiles of 128 at msz 2000) leaves each CU a single workgroup
+  hipStream_t s3 = st;
+  if (c->opt.prepw_streams && n >= 1024) {
+    if (!c->stream3) {
+      LRN_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+      LRN_HIP(c, hipEventCreateWithFlags(&c->evC, hipEventDisableTiming));
+      LRN_HIP(c, hipEventCreateWithFlags(&c->evD, hipEventDisableTiming));
+    }
+    s3 = c->stream3;
+  }
   auto one_step = [&](double a) -> int {
     const double *Pk = Yc, *Ptk = Ytc;                    // Z = I: P = Y
-    if (!z_is_eye) { LRN_TRY(gemm_nt(st, n, Zc, Ytc, Pm, 0, 1.0, Pt)); Pk = Pm; Ptk = Pt; }
+    if (!z_is_eye) { LRN_TRY(prod(st, Zc, Ytc, Pm, Pt)); Pk = Pm; Ptk = Pt; }
     hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Pk, n, a, Tm, part);
     hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, part, npart, res + k);
     hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Ptk, n, a, Tt, (double*)nullptr);
-    LRN_TRY(gemm_nt(st, n, Yc, Tt, Yn, 0, 1.0, Ytn));                                  // Y T
+    if (!z_is_eye && s3 != st) {
+      LRN_HIP(c, hipEventRecord(c->evC, st));                                          // T, T' are final
+      LRN_HIP(c, hipStreamWaitEvent(s3, c->evC, 0));
+      LRN_TRY(prod(s3, Tm, Ztc, Zn, Ztn));                                             // T Z
+      LRN_HIP(c, hipEventRecord(c->evD, s3));
+    }
+    LRN_TRY(prod(st, Yc, Tt, Yn, Ytn));                                                // Y T
     if (z_is_eye) {
       LRN_HIP(c, hipMemcpyAsync(Zn, Tm, mm, hipMemcpyDeviceToDevice, st));
       LRN_HIP(c, hipMemcpyAsync(Ztn, Tt, mm, hipMemcpyDeviceToDevice, st));
       z_is_eye = false;
+    } else if (s3 != st) {
+      LRN_HIP(c, hipStreamWaitEvent(st, c->evD, 0));
     } else {
-      LRN_TRY(gemm_nt(st, n, Tm, Ztc, Zn, 0, 1.0, Ztn));                               // T Z
+      LRN_TRY(prod(st, Tm, Ztc, Zn, Ztn));                                             // T Z
     }
     std::swap(Yc, Yn); std::swap(Ytc, Ytn); std::swap(Zc, Zn); std::swap(Ztc, Ztn);
     ++k;
     return LRN_OK;
   };
-  while (k < maxit && 1.0 - ell > 1e-9) {
+  // scaled steps until the assumed interval is [1 - 5e-4, 1], then two plain ones: 3 (5e-4)^2 -> 1e-12
+  while (k < maxit && 1.0 - ell > 5e-4) {
     const double a = std::sqrt(3.0 / (1.0 + ell + ell * ell));
     ell = 0.5 * a * ell * (3.0 - a * a * ell * ell);
     LRN_TRY(one_step(a));
   }
-  if (k < maxit) LRN_TRY(one_step(1.0));
+  for (int e = 0; e < 2 && k < maxit; ++e) LRN_TRY(one_step(1.0));
   std::vector<double> hres(maxit + 2, 0.0);
   bool ok = false;
   for (;;) {
@@ -509,10 +562,10 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
     LRN_HIP(c, hipStreamSynchronize(st));
     const double rl = hres[k - 1];           // ||I - P|| at the START of the last step: the step squares it
     if (!(rl == rl) || rl > 1e30) break;     // NaN / overflow: not a matrix this iteration handles
-    if (rl <= 3e-8) { ok = true; break; }
-    if (k + 2 > maxit) break;
+    if (rl <= 1e-6) { ok = true; break; }    // (the literal iteration is quadratic down to 1e-13: the last step leaves <= 1e-12)
+    if (k + 1 > maxit) break;
     LRN_TRY(one_step(1.0));
-    LRN_TRY(one_step(1.0));
+    if (rl > 1e-2 && k + 1 <= maxit) LRN_TRY(one_step(1.0));
   }
   c->counts["ns_steps"] = k;
   toc(c, "prepw_ns");
@@ -533,7 +586,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   if (Zc != Z) LRN_HIP(c, hipMemcpyAsync(Z, Zc, mm, hipMemcpyDeviceToDevice, st));
   // W = L_X K^-1/2 L_X' = L_X Z L_X' / sqrt(c)                                          (prepare_W.jl:64)
   LRN_TRY(gemm_nt(st, n, LX, Ztc, Pm, 0, 1.0));
-  LRN_TRY(gemm_nt(st, n, Pm, LX, b.W.as<double>(), GEMM_TRI_LOWER | GEMM_C_MIRROR, 1.0 / std::sqrt(b.ns_c)));
+  LRN_TRY(gemm_nt_sym(st, n, Pm, LX, b.W.as<double>(), 1.0 / std::sqrt(b.ns_c)));
   // (K/c)^-1 = Zh^2: the sigma_mu S^-1 term of the corrector in the L_X basis
   LRN_TRY(gemm_nt(st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
   if (two) {                                                  // join: Si is complete when this returns
