@@ -275,46 +275,16 @@ def main():
     dely = torch.zeros(nvar, dtype=torch.float64, device="cuda")
     from loraine_jl_amd import sharding
     if sharded:
-        dev.set_shard(rank, world)
-        # every rank must enter the same collective: agree on the exchange before the first assembly (free device
-        # memory, which the choice depends on, differs between ranks) and check the outcome of every assembly
-        plan = sharding.agree_on_plan(dev)
-        shard = torch.zeros(dev.shard_doubles(), dtype=torch.float64, device="cuda")
-        gathered = torch.zeros(dev.shard_doubles() * world, dtype=torch.float64, device="cuda")
-        hfull = torch.zeros(nvar * nvar, dtype=torch.float64, device="cuda")
+        # the exchange lives in the library (csrc/comm.hip): RCCL communicator created from a unique id that travels
+        # through the launcher's process group; every lrn_schur_assemble then agrees on the path (first call), reduces a
+        # status word every rank enters, and all-reduces / all-gathers on the library's stream.  With the rehearsal
+        # backend (gloo, ranks sharing one GPU) the same entry points run over host callbacks.
+        transport = dev.comm_init_torch(rank, world)
     from loraine_jl_amd._capi import ptr
     lib = dev.lib
 
-    t_exchange = [0.0]
-
     def step():
-        dev.schur_assemble(0)                                   # makeBBBBs on the owned columns
-        te = time.perf_counter()
-        partial = sharding.check_same_exchange(dev) if sharded else False
-        if sharded and partial:
-            # Cholesky path: the ranks split the columns of the matrix variable, each holds a partial sum of H
-            dev.schur_export_full(hfull)
-            if backend == "nccl":
-                dist.all_reduce(hfull)                          # RCCL over xGMI, nvar^2 doubles
-                torch.cuda.current_stream().synchronize()
-            else:
-                h_host = hfull.cpu()
-                dist.all_reduce(h_host)
-                hfull.copy_(h_host)
-                torch.cuda.synchronize()
-            dev.schur_import_full(hfull)
-        elif sharded:
-            dev.schur_export_shard(shard)
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, shard)    # RCCL over xGMI
-                torch.cuda.current_stream().synchronize()
-            else:
-                g_host = torch.empty(gathered.shape, dtype=torch.float64)
-                dist.all_gather_into_tensor(g_host, shard.cpu())
-                gathered.copy_(g_host)
-                torch.cuda.synchronize()
-            dev.schur_import_all(gathered)
-        t_exchange[0] += time.perf_counter() - te               # (includes waiting for the slowest rank's assembly)
+        dev.schur_assemble(0)                                   # makeBBBBs on the owned share + the exchange
         info = dev.schur_factor()                               # cholesky(BBBB)
         assert info == 0, f"Schur matrix not PD (info={info})"
         dev._chk(lib.lrn_schur_solve(dev.h, ptr(h_pred), ptr(dely)), "solve")   # predictor
@@ -336,7 +306,6 @@ def main():
         step()
     dev.set_option("profile", 1)          # per-kernel HIP-event timing on the library's stream
     dev.reset_timing()
-    t_exchange[0] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -400,7 +369,7 @@ def main():
             kpat = "gemm_f64_lds_kernel<true>"
         achieved = alg_flops_launch / (t1 * 1e-3) / 1e12
         phases = {k: dev.timing(k) / args.steps
-                  for k in ("wchol", "gemm1", "gemm2", "gemm3", "reduce3", "assemble", "factor", "solve")}
+                  for k in ("wchol", "gemm1", "gemm2", "gemm3", "reduce3", "assemble", "exchange", "factor", "solve")}
         cols = sharding.column_range(msz, nvar, rank, world) if chol_path else None
         return {"rank": rank, "chol_path": chol_path, "via_l": via_l, "kpat": kpat, "phases": phases,
                 "columns": list(cols) if cols else None,
@@ -448,7 +417,8 @@ def main():
                                 "gemm1_ms": r_["phases"]["gemm1"], "gemm2_ms": r_["phases"]["gemm2"],
                                 "gemm3_ms": r_["phases"]["gemm3"], "roofline_frac": r_["roofline"]["frac"]}
                                for r_ in reports]
-            out["exchange_ms_per_step"] = t_exchange[0] / args.steps * 1e3
+            out["exchange_ms_per_step"] = dev.timing("exchange") / args.steps     # status reduction excluded: HIP events around the collective
+            out["exchange_transport"] = transport
         if world == 1 and not args.no_cpu_baseline:
             dev.close()
             out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7, args.cpu_msz2,

@@ -194,6 +194,31 @@ int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top
  * current scaling of the block is the eigen-free one, and c = lrn_get_timing("ns_c") its scale. */
 int lrn_dbg_get_block(lrn_ctx* ctx, int il, const char* name, double* out, int* flag);
 
+/* ---- multi-GPU: one process per GPU, the exchange inside the library ---------------------------------------
+ * The reference is one process (no MPI/NCCL); a sharded run keeps its predictor / corrector loop
+ * (src/predictor_corrector.jl:24-40,119-139) unchanged and only creates a communicator:
+ *   rank 0: lrn_comm_unique_id(id) -> the launcher distributes the 128 bytes -> every rank: lrn_comm_init(ctx, id, rank, world)
+ * (ncclCommInitRank on the context's device; implies lrn_set_shard).  From then on
+ *   lrn_schur_assemble  agrees on the assembly path with the other ranks (first call), assembles the rank's share, reduces
+ *                       a status word that EVERY rank enters (a rank that failed makes all ranks return an error, nobody
+ *                       is left waiting in a collective) and exchanges on the library's stream: one all-reduce of the
+ *                       lower triangle, nvar (nvar + 1) / 2 doubles, on the Cholesky path of dense data; one all-gather
+ *                       of the owned column blocks otherwise (makeBBBB.jl:24-36, then the replicated cholesky :57);
+ *   lrn_pcg, lrn_matvec apply the operator as this rank's rows of W M W plus one all-reduce of the nvar-vector
+ *                       (Solvers.jl:582-614) -- the CG recurrence stays on the device on every rank.
+ * lrn_comm_init_host: the same entry points over callbacks that reduce / gather HOST buffers (ranks sharing one GPU,
+ * launchers whose fabric is MPI or gloo on the CPU); op: 0 sum, 1 min, 2 max; callbacks return 0 on success.
+ * lrn_comm_allreduce: in-place all-reduce of `count` doubles (host or device pointer) on the communicator, for the
+ * host loop's own replicated scalars. */
+typedef int (*lrn_host_allreduce_fn)(void* user, double* buf, int64_t count, int op);
+typedef int (*lrn_host_allgather_fn)(void* user, const double* send, double* recv, int64_t count_per_rank);
+int lrn_comm_unique_id(void* id128);
+int lrn_comm_init(lrn_ctx* ctx, const void* id128, int rank, int world);
+int lrn_comm_init_host(lrn_ctx* ctx, int rank, int world, lrn_host_allreduce_fn allreduce,
+                       lrn_host_allgather_fn allgather, void* user);
+int lrn_comm_destroy(lrn_ctx* ctx);
+int lrn_comm_allreduce(lrn_ctx* ctx, double* buf, int64_t count, int op);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* milliseconds of the named phase in the last call that ran it, measured with HIP events
  * on the context's stream ("gemm1","gemm2","gemm3","sparse","assemble","factor","solve",...);

@@ -54,6 +54,11 @@ SIGNATURES = {
     "lrn_prec_setup": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, PI]),
     "lrn_prec_apply": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     "lrn_pcg": (C.c_int, [c_ctx, C.c_void_p, C.c_double, C.c_int, C.c_void_p, PI, PI]),
+    "lrn_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "lrn_comm_init": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "lrn_comm_init_host": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lrn_comm_destroy": (C.c_int, [c_ctx]),
+    "lrn_comm_allreduce": (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int]),
     "lrn_ip_set_c": (C.c_int, [c_ctx, C.c_int, C.c_void_p]),
     "lrn_ip_set_iterate": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_void_p]),
     "lrn_ip_get_iterate": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_void_p]),

@@ -47,6 +47,7 @@ int lrn_destroy(lrn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   prec_free(c);
+  comm_free(c);
   lrn_free_model(c);
   release(c->info_dev);
   release(c->scratch);
@@ -160,7 +161,15 @@ int lrn_set_lin(lrn_ctx* c, const double* X_lin, const double* S_lin_inv) {
 int lrn_schur_assemble(lrn_ctx* c, int mode, double* H_out) {
   if (!c) return LRN_ERR_ARG;
   LRN_HIP(c, hipSetDevice(c->device));
-  LRN_TRY(schur_assemble(c, mode));
+  if (c->comm && c->world > 1 && c->pos_space) {
+    // multi-GPU (lrn_comm_init): agree on the assembly path once, assemble the owned share, then -- whatever the local
+    // outcome -- enter the status reduction and the exchange on the library's stream
+    LRN_TRY(comm_agree_plan(c, mode));
+    const int rc = schur_assemble(c, mode);
+    LRN_TRY(comm_schur_exchange(c, rc));
+  } else {
+    LRN_TRY(schur_assemble(c, mode));
+  }
   if (H_out) return schur_get(c, H_out);
   return LRN_OK;
 }

@@ -910,8 +910,16 @@ int pcg_dev(lrn_ctx* c, const double* b, double tol, int maxit, double* x, int* 
   if (residual_0 <= tol) { *exit_code = 2; *iters = 0; return LRN_OK; }
   LRN_TRY(prec_apply_dev(c, r, z, tmpv));
   LRN_HIP(c, hipMemcpyAsync(p, z, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  const bool sharded = c->comm && c->world > 1;
   for (int it = 1; it <= maxit; ++it) {
-    LRN_TRY(matvec_dev(c, p, Ap));
+    if (sharded) {
+      // one process per GPU: this rank's rows of W M W, then ONE all-reduce of the nvar-vector on this stream -- the
+      // recurrence below is replicated and stays on the device, as on one GPU
+      LRN_TRY(matvec_partial_dev(c, p, Ap, c->rank, c->world));
+      LRN_TRY(comm_allreduce(c, Ap, n, 0));
+    } else {
+      LRN_TRY(matvec_dev(c, p, Ap));
+    }
     ++nmv;
     hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1024), 0, st, p, Ap, z, r, x, n, scal);
     LRN_HIP(c, hipMemcpyAsync(hs, scal, 5 * 8, hipMemcpyDeviceToHost, st));
@@ -938,7 +946,12 @@ extern "C" int lrn_matvec(lrn_ctx* c, const double* x, double* Ax) {
   const int n = c->nvar;
   LRN_TRY(copy_in(c, c->v0.p, x, (size_t)n * 8));
   tic(c);
-  LRN_TRY(matvec_dev(c, c->v0.as<double>(), c->v1.as<double>()));
+  if (c->comm && c->world > 1) {
+    LRN_TRY(matvec_partial_dev(c, c->v0.as<double>(), c->v1.as<double>(), c->rank, c->world));
+    LRN_TRY(comm_allreduce(c, c->v1.as<double>(), n, 0));
+  } else {
+    LRN_TRY(matvec_dev(c, c->v0.as<double>(), c->v1.as<double>()));
+  }
   toc(c, "matvec");
   return copy_out(c, Ax, c->v1.p, (size_t)n * 8);
 }

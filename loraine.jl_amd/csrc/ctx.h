@@ -5,7 +5,7 @@
 #include "chol.h"
 #include "lrn_common.h"
 
-namespace lrn { struct Prec; }
+namespace lrn { struct Prec; struct Comm; }
 
 struct LmiBlock {
   int msz = 0;
@@ -151,6 +151,8 @@ struct lrn_ctx {
   lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lzbuf2, lxbuf, ezbuf;
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
+  // multi-GPU communicator (comm.hip; lrn_comm_init / lrn_comm_init_host)
+  lrn::Comm* comm = nullptr;
 };
 
 namespace lrn {
@@ -163,6 +165,12 @@ int copy_out(lrn_ctx* c, void* dst, const void* src_dev, size_t bytes);   // dst
 void tic(lrn_ctx* c);
 void toc(lrn_ctx* c, const char* key);
 
+// comm.hip
+int comm_allreduce(lrn_ctx* c, double* buf_dev, long count, int op);     // in place on c->stream; op 0 sum, 1 min, 2 max
+int comm_allgather(lrn_ctx* c, const double* send_dev, double* recv_dev, long count);
+int comm_schur_exchange(lrn_ctx* c, int rc_local);
+int comm_agree_plan(lrn_ctx* c, int mode);
+void comm_free(lrn_ctx* c);
 // schur.hip
 int schur_assemble(lrn_ctx* c, int mode);
 int schur_plan(lrn_ctx* c, int mode);

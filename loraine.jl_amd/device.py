@@ -52,6 +52,82 @@ class Device:
     def set_shard(self, rank, world):
         self._chk(self.lib.lrn_set_shard(self.h, int(rank), int(world)), "set_shard")
 
+    # ------------------------------------------------------------------ multi-GPU communicator (csrc/comm.hip)
+    def comm_unique_id(self):
+        """RCCL unique id (128 bytes) -- rank 0 creates it, the launcher hands it to every rank."""
+        buf = (C.c_ubyte * 128)()
+        rc = self.lib.lrn_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise LoraineHipError(f"lrn_comm_unique_id failed ({rc})")
+        return bytes(buf)
+
+    def comm_init(self, uid, rank, world):
+        """ncclCommInitRank on this context's device: the exchanges of lrn_schur_assemble / lrn_pcg / lrn_matvec run
+        inside the library from now on."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(uid))
+        self._chk(self.lib.lrn_comm_init(self.h, C.cast(buf, C.c_void_p), int(rank), int(world)), "lrn_comm_init")
+
+    def comm_init_host(self, rank, world, allreduce, allgather):
+        """The same entry points over host callbacks: allreduce(np_array, op) reduces in place (op 0 sum, 1 min,
+        2 max), allgather(send, recv) fills recv (world * len(send))."""
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+
+        def _ar(_user, buf, count, op):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)), int(op))
+                return 0
+            except Exception as e:          # noqa: BLE001 -- an exception must not unwind through the C frames
+                print(f"[loraine.jl_amd] host all-reduce callback: {e!r}", flush=True)
+                return 1
+
+        def _ag(_user, send, recv, count):
+            try:
+                allgather(np.ctypeslib.as_array(send, shape=(int(count),)),
+                          np.ctypeslib.as_array(recv, shape=(int(count) * int(world),)))
+                return 0
+            except Exception as e:          # noqa: BLE001
+                print(f"[loraine.jl_amd] host all-gather callback: {e!r}", flush=True)
+                return 1
+
+        self._comm_cb = (AR(_ar), AG(_ag))              # keep the trampolines alive as long as the communicator
+        self._chk(self.lib.lrn_comm_init_host(self.h, int(rank), int(world), C.cast(self._comm_cb[0], C.c_void_p),
+                                              C.cast(self._comm_cb[1], C.c_void_p), None), "lrn_comm_init_host")
+
+    def comm_init_torch(self, rank, world, group=None):
+        """Create the library's communicator from a torch.distributed process group: RCCL when the group's backend is
+        nccl (the unique id travels through the group), host-staged callbacks over the group otherwise (gloo: ranks
+        that share a GPU, CPU-only fabrics)."""
+        import torch
+        import torch.distributed as dist
+        if world <= 1 and not dist.is_initialized():
+            self.comm_init(self.comm_unique_id(), 0, 1)
+            return "rccl"
+        if dist.get_backend(group) == "nccl":
+            box = [self.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            self.comm_init(box[0], rank, world)
+            return "rccl"
+        ops = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}
+
+        def ar(a, op):
+            dist.all_reduce(torch.from_numpy(a), op=ops[op], group=group)
+
+        def ag(send, recv):
+            dist.all_gather_into_tensor(torch.from_numpy(recv), torch.from_numpy(send), group=group)
+
+        self.comm_init_host(rank, world, ar, ag)
+        return "host"
+
+    def comm_destroy(self):
+        self._chk(self.lib.lrn_comm_destroy(self.h), "lrn_comm_destroy")
+        self._comm_cb = None
+
+    def comm_allreduce(self, arr, op=0):
+        arr = f64(arr)
+        self._chk(self.lib.lrn_comm_allreduce(self.h, ptr(arr), int(arr.size), int(op)), "lrn_comm_allreduce")
+        return arr
+
     def timing(self, key):
         v = C.c_double(0.0)
         self.lib.lrn_get_timing(self.h, key.encode(), C.byref(v))

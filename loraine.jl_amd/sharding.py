@@ -147,7 +147,9 @@ def column_range(msz, nd, rank, world):
 
 
 def agree_on_plan(dev, group=None, mode=0):
-    """Every rank must enter the same collective after the assembly.  The choice between the two exchanges depends on
+    """(Executable specification of `comm_agree_plan` in csrc/comm.hip, which the product path runs inside
+    lrn_schur_assemble; kept for the CPU tests over gloo.)
+    Every rank must enter the same collective after the assembly.  The choice between the two exchanges depends on
     free device memory, which differs between ranks: all-reduce (MIN) each rank's own `lrn_schur_plan` and pin the
     result on every rank (option "schur_plan").  Returns the agreed plan (1 all-reduce of partial sums, 0 all-gather
     of column blocks)."""
@@ -163,7 +165,9 @@ def agree_on_plan(dev, group=None, mode=0):
 
 
 def check_same_exchange(dev, group=None):
-    """After the assembly: all ranks hold the same kind of result (partial sums or column blocks)?  One tiny
+    """(Specification of the status reduction in `comm_schur_exchange`, csrc/comm.hip -- there a rank whose assembly
+    FAILED enters it too, and every rank then returns the error.)
+    After the assembly: all ranks hold the same kind of result (partial sums or column blocks)?  One tiny
     all-reduce that every rank enters unconditionally; a disagreement (a rank whose W could not be factored, a
     plan that was not pinned) raises on every rank instead of pairing an all-reduce with an all-gather."""
     import torch
@@ -177,57 +181,6 @@ def check_same_exchange(dev, group=None):
         raise RuntimeError("ranks disagree on the Schur exchange (partial sums on some, column blocks on others): "
                            "refusing to enter mismatched collectives")
     return bool(hi)
-
-
-class SchurExchange:
-    """The collective step of the sharded direct solve (product path, GPU tensors)."""
-
-    def __init__(self, dev, rank, world, group=None, mode=0):
-        import torch
-        self.dev, self.rank, self.world, self.group = dev, rank, world, group
-        dev.set_shard(rank, world)
-        # construct BEFORE the first sharded assembly: the plan the ranks agree on here decides its path
-        self.plan = agree_on_plan(dev, group, mode) if world > 1 else 0
-        n = dev.shard_doubles()
-        self.shard = torch.zeros(n, dtype=torch.float64, device="cuda")
-        self.gathered = torch.zeros(n * world, dtype=torch.float64, device="cuda")
-
-    def allreduce_full(self):
-        """Dense data through the Cholesky factor of W: every rank holds a partial sum of the whole matrix
-        (the ranks split the columns of the matrix variable) -- one all-reduce of nvar^2 doubles."""
-        import torch
-        import torch.distributed as dist
-        n = self.dev.nvar
-        if getattr(self, "full", None) is None or self.full.numel() != n * n:
-            self.full = torch.zeros(n * n, dtype=torch.float64, device="cuda")
-        self.dev.schur_export_full(self.full)
-        if dist.get_backend(self.group) == "gloo":        # rehearsal on a one-GPU box: stage through the host
-            h_ = self.full.cpu()
-            dist.all_reduce(h_, group=self.group)
-            self.full.copy_(h_)
-            torch.cuda.synchronize()
-        else:
-            dist.all_reduce(self.full, group=self.group)   # RCCL over xGMI
-            torch.cuda.current_stream().synchronize()
-        self.dev.schur_import_full(self.full)
-
-    def allgather(self):
-        import torch
-        import torch.distributed as dist
-        self.dev.set_shard(self.rank, self.world)
-        partial = check_same_exchange(self.dev, self.group) if self.world > 1 else self.dev.schur_is_partial_sum()
-        if partial:
-            return self.allreduce_full()
-        self.dev.schur_export_shard(self.shard)
-        if dist.get_backend(self.group) == "gloo":        # rehearsal on a one-GPU box: stage through the host
-            g_host = torch.empty(self.gathered.shape, dtype=torch.float64)
-            dist.all_gather_into_tensor(g_host, self.shard.cpu(), group=self.group)
-            self.gathered.copy_(g_host)
-            torch.cuda.synchronize()
-        else:
-            dist.all_gather_into_tensor(self.gathered, self.shard, group=self.group)    # RCCL over xGMI
-            torch.cuda.current_stream().synchronize()
-        self.dev.schur_import_all(self.gathered)
 
 
 # ------------------------------------------------------------------ kit = 1: sharded PCG
@@ -264,84 +217,28 @@ def pcg_allreduce(matvec_partial, allreduce_sum, precon, b, tol, max_iter, xp=np
     return x, -2, max_iter
 
 
-class ShardedCG:
-    """Product binding of `pcg_allreduce`: vectors are CUDA tensors, the partial mat-vec and the
-    preconditioner are C-ABI calls on device pointers, the all-reduce is RCCL."""
-
-    def __init__(self, dev, rank, world, group=None):
-        self.dev, self.rank, self.world, self.group = dev, rank, world, group
-        dev.set_shard(rank, world)
-
-    def solve(self, h, tol, max_iter=10000):
-        import torch
-        import torch.distributed as dist
-        from ._capi import ptr
-        dev = self.dev
-        b = torch.as_tensor(np.asarray(h, float)).cuda()
-
-        # the library works on its own HIP stream: torch's stream must have finished writing a tensor
-        # before its pointer is handed over (_capi.ptr() synchronises as well; the library's calls are
-        # blocking, so the way back is safe)
-        def mv(p):
-            out = torch.empty_like(p)
-            torch.cuda.current_stream().synchronize()
-            dev._chk(dev.lib.lrn_matvec_partial(dev.h, ptr(p), ptr(out)), "lrn_matvec_partial")
-            return out
-
-        gloo = self.world > 1 and dist.get_backend(self.group) == "gloo"
-
-        def ar(v):
-            if gloo:                                       # rehearsal: host-staged
-                h_ = v.cpu()
-                dist.all_reduce(h_, group=self.group)
-                v.copy_(h_)
-            elif self.world > 1:
-                dist.all_reduce(v, group=self.group)       # RCCL
-            return v
-
-        def pc(r):
-            out = torch.empty_like(r)
-            torch.cuda.current_stream().synchronize()
-            dev._chk(dev.lib.lrn_prec_apply(dev.h, ptr(r), ptr(out)), "lrn_prec_apply")
-            return out
-
-        x, ec, it = pcg_allreduce(mv, ar, pc, b, tol, max_iter, xp=torch)
-        return x.cpu().numpy(), ec, it
-
-
 class DistributedHotPath:
-    """Attach to a solver (`solvers.MySolver` / `resident.ResidentSolver`) to run the interior-point
-    loop with one process per GPU: every rank drives the same (replicated, deterministic) iteration and
-    only the hot path is sharded -- kit=0: owned Schur column blocks + one all-gather before the
-    replicated Cholesky; kit=1: partial mat-vec + one all-reduce of an nvar-vector per CG iteration
-    (SURVEY.md 8e).  prepare_W, find_step and the preconditioner setup are replicas."""
+    """Attach to a solver (`solvers.MySolver` / `resident.ResidentSolver`) to run the interior-point loop with one
+    process per GPU: every rank drives the same (replicated, deterministic) iteration and only the hot path is sharded
+    (SURVEY.md 8e).  All this class does is create the library's communicator (csrc/comm.hip: RCCL, or host callbacks
+    over a gloo group): from then on `lrn_schur_assemble` agrees on the path, checks every rank's outcome and exchanges
+    on the library's stream (kit=0), and `lrn_pcg` all-reduces its nvar-vector (kit=1) -- the loop itself is unchanged,
+    which is what a Julia host gets from `LoraineHIP.comm_init!` as well.  prepare_W, find_step and the preconditioner
+    setup are replicas."""
 
     def __init__(self, solver, rank, world, group=None):
         self.rank, self.world, self.group = int(rank), int(world), group
-        self._exchange = None
-        self._cg = None
         solver.dist = self
         # the C library shards Schur columns in sigma-position space, which exists for one LMI block;
         # multi-block problems assemble replicated (every rank the whole matrix, no exchange)
         self.shard_schur = self.world > 1 and (solver.kit == 1 or solver.model.nlmi == 1)
         if self.shard_schur:
-            solver.dev.set_shard(self.rank, self.world)     # assembly from now on covers the owned column blocks
-            if solver.kit == 0:
-                # the ranks agree on the exchange BEFORE the first assembly (SchurExchange pins the plan)
-                self._exchange = SchurExchange(solver.dev, self.rank, self.world, self.group,
-                                               mode=-1 if getattr(solver, "datarank", 0) == -1 else 0)
+            self.transport = solver.dev.comm_init_torch(self.rank, self.world, group)
         else:
             solver.dev.set_shard(0, 1)
 
     def allgather(self, dev):
-        if not self.shard_schur:
-            return
-        if self._exchange is None:
-            self._exchange = SchurExchange(dev, self.rank, self.world, self.group)
-        self._exchange.allgather()
+        """(The exchange happened inside lrn_schur_assemble.)"""
 
     def pcg(self, dev, h, tol, max_iter=10000):
-        if self._cg is None:
-            self._cg = ShardedCG(dev, self.rank, self.world, self.group)
-        dev.set_shard(self.rank, self.world)
-        return self._cg.solve(h, tol, max_iter)
+        return dev.pcg(h, tol, max_iter)

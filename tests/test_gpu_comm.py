@@ -1,0 +1,79 @@
+"""The multi-GPU exchange inside the C library (csrc/comm.hip) with two ranks that share this box's one GPU: the
+communicator's host transport over a gloo group carries exactly the calls RCCL carries on a multi-GPU node
+(lrn_comm_init_host vs lrn_comm_init).  Whole interior-point solves: kit=0 general data (Schur column blocks +
+all-gather), kit=0 dense data on the Cholesky path (column split of the matrix variable + all-reduce of the lower
+triangle), rank-one data, kit=1 (partial operator + all-reduce of an nvar-vector inside lrn_pcg)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import loraine_jl_amd
+    from loraine_jl_amd import resident
+    from loraine_jl_amd.model import model_from_sdpa
+    from loraine_jl_amd.sharding import DistributedHotPath
+    from loraine_jl_amd.synthetic import LowRankProblem, synthetic_dense_solver
+    dev = loraine_jl_amd.Device(0)
+    out = {}
+    cases = [("theta1", lambda: model_from_sdpa(os.path.join(GOLD, "theta1.dat-s")), dict(kit=0, eDIMACS=1e-6)),
+             ("maxG11", lambda: model_from_sdpa(os.path.join(GOLD, "maxG11.dat-s"), datarank=-1), dict(kit=0, datarank=-1)),
+             ("theta1_cg", lambda: model_from_sdpa(os.path.join(GOLD, "theta1.dat-s")),
+              dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)),
+             ("lowrank_cg", lambda: LowRankProblem(60, 120, 4, seed=7).model(), dict(kit=1, preconditioner=2, erank=4, eDIMACS=1e-6))]
+    for name, mk, opts in cases:
+        model = mk()
+        solver, ha = resident.load(model, dict(opts, verb=0), device=dev)
+        hot = DistributedHotPath(solver, rank, world)
+        solver.solve(ha)
+        out[name] = dict(status=solver.status, iters=solver.iter, obj=-(float(model.b @ np.ravel(solver.y)) - model.b_const),
+                         transport=getattr(hot, "transport", None), exchanges=dev.count("exchange"))
+        dev.comm_destroy()
+    # dense data: the Cholesky path splits the columns of the matrix variable, the exchange is an all-reduce
+    dev.set_option("schur_chol", 1)            # (auto takes the path from msz 256 on)
+    solver, ha = synthetic_dense_solver(dev, 96, 160, seed=11, options=dict(kit=0, verb=0))
+    hot = DistributedHotPath(solver, rank, world)
+    solver.solve(ha)
+    out["dense"] = dict(status=solver.status, iters=solver.iter, obj=float(solver.primal_obj),
+                        schur_chol=dev.count("schur_chol"), plan=dev.count("schur_plan_agreed"))
+    dev.comm_destroy()
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_solve_through_the_library_communicator(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    for name, expect in (("theta1", 23.0), ("maxG11", 629.1648), ("theta1_cg", 23.0)):
+        for k in range(2):
+            assert r[k][name]["status"] == 1
+            assert r[k][name]["obj"] == pytest.approx(expect, rel=3e-5)
+            assert r[k][name]["transport"] == "host"
+        assert r[0][name]["obj"] == r[1][name]["obj"]              # the replicated iteration stays in lock-step
+        assert r[0][name]["iters"] == r[1][name]["iters"]
+    assert r[0]["theta1"]["exchanges"] > 0                         # one exchange per assembly, inside lrn_schur_assemble
+    assert r[0]["lowrank_cg"]["status"] == 1 and r[0]["lowrank_cg"]["obj"] == r[1]["lowrank_cg"]["obj"]
+    assert r[0]["dense"]["status"] == 1 and r[0]["dense"]["obj"] == r[1]["dense"]["obj"]
+    assert r[0]["dense"]["iters"] == r[1]["dense"]["iters"]

@@ -279,13 +279,54 @@ def test_row_sharded_matvec_sums_to_full(dev):
         acc += part
     dev.set_shard(0, 1)
     assert relerr(acc, full) < 1e-13
-    # and the product-side sharded PCG driver (world = 1 degenerates to the plain operator)
-    from loraine_jl_amd.sharding import ShardedCG
-    dev.prec_setup(2, 1, 1) if False else dev.prec_setup(0, 1, 1)
+    # the same sum inside the library: with a communicator lrn_matvec is "this rank's share + all-reduce".  Three ranks
+    # emulated in this process: the host all-reduce callback adds the shares a twin context computes for ranks 1 and 2
+    import loraine_jl_amd as _l
+    twin = _l.Device(0)
+    twin.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    twin.set_scaling(0, s.W[0], s.G[0])
+    state = {}
+
+    def allreduce(buf, op):
+        assert op == 0 and buf.size == model.n
+        for r in (1, 2):
+            twin.set_shard(r, 3)
+            part = np.zeros(model.n)
+            twin._chk(twin.lib.lrn_matvec_partial(twin.h, ptr(state["x"]), ptr(part)), "lrn_matvec_partial")
+            buf += part
+
+    dev.comm_init_host(0, 3, allreduce, lambda send, recv: None)
+    try:
+        state["x"] = x
+        assert relerr(dev.matvec(x), full) < 1e-13
+    finally:
+        dev.comm_destroy()
+        twin.close()
+    assert relerr(dev.matvec(x), full) == 0.0          # and back to the plain operator
+
+
+def test_rccl_communicator_world_size_one(dev):
+    """lrn_comm_unique_id / lrn_comm_init (ncclCommInitRank on the context's device) and a collective on the library's
+    stream with a communicator of one rank; the hot path is unchanged by it (kit=0 assembly + solve, kit=1 PCG)."""
+    model = lo.model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
+    s = _iterate(model, dict(kit=0), 3)
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    dev.set_scaling(0, s.W[0], s.G[0])
+    dev.prec_setup(0, 1, 1)
     h = np.random.default_rng(4).standard_normal(model.n)
-    xs, ec, it = ShardedCG(dev, 0, 1).solve(h, 1e-8)
-    xg, ec2, it2 = dev.pcg(h, 1e-8)
-    assert ec == ec2 == 30 and abs(it - it2) <= 1 and relerr(xs, xg) < 1e-6
+    x0, ec0, it0 = dev.pcg(h, 1e-8)
+    H0 = dev.schur_assemble(0, want_H=True)
+    uid = dev.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    dev.comm_init(uid, 0, 1)
+    try:
+        v = np.arange(5, dtype=float)
+        assert (dev.comm_allreduce(v.copy(), 0) == v).all()       # ncclAllReduce over one rank
+        x1, ec1, it1 = dev.pcg(h, 1e-8)
+        H1 = dev.schur_assemble(0, want_H=True)
+    finally:
+        dev.comm_destroy()
+    assert (ec1, it1) == (ec0, it0) and (x1 == x0).all() and (H1 == H0).all()
 
 
 @pytest.mark.parametrize("case", ["thetaG11", "lowrank"])
