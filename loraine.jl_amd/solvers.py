@@ -38,7 +38,19 @@ def _mat(v):
 
 
 def _eigmin(M):
+    # Julia's `eigmin` hands a matrix with NaN / Inf entries to LAPACK and gets NaN back; SciPy raises.  A diverging run
+    # (unbounded problem: fuzz seed 3024, objective -1e18) must end in the reference's own exit -- the step lengths turn
+    # NaN, cholesky(X) fails and try_cholesky gives up with status 4 (prepare_W.jl:17-21) -- not in a Python exception.
+    if not np.isfinite(M).all():
+        return float("nan")
     return float(sla.eigvalsh(M, subset_by_index=[0, 0])[0])
+
+
+def _step(lam, tau):
+    """predictor_corrector.jl:274-278 with Julia's NaN semantics (min(1, NaN) is NaN there, 1.0 in Python)."""
+    if lam != lam:
+        return float("nan")
+    return 0.99 if lam > -1e-6 else min(1.0, -tau / lam)
 
 
 def _fro(M):
@@ -335,7 +347,7 @@ class MySolver:
             for name, Mb in (("alpha", dXb), ("beta", dSb)):
                 Q = dd[None, :] * Mb * dd[:, None]
                 lam = _eigmin(0.5 * (Q + Q.T))
-                getattr(self, name)[i] = 0.99 if lam > -1e-6 else min(1.0, -self.tau / lam)
+                getattr(self, name)[i] = _step(lam, self.tau)
         if m.nlin > 0:
             self._find_step_lin()
         else:

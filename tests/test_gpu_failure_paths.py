@@ -109,3 +109,29 @@ def test_tru9_default_matches_the_oracle():
     assert o.solver.status == 1 and abs(o.solver.iter - 28) <= 1
     assert o.solver.regcount == 0
     assert o.objective_value() == pytest.approx(0.0597530923, rel=2e-7)
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_unbounded_rank_one_problem_ends_in_a_reference_status(resident, monkeypatch):
+    """Fuzz seed 3024 of the rank-one generator is unbounded: the objective runs to -1e18 and the iterates lose their
+    finite entries.  The reference then leaves through try_cholesky's give-up (status 4, prepare_W.jl:17-21) or the
+    iteration limit -- never through an exception of the host language (round 2: the host driver raised ValueError
+    from SciPy's eigvalsh on a NaN matrix)."""
+    import tools.fuzz_parity as F
+    monkeypatch.setattr(F, "RANK1", True)
+    A, b, d_lin, C_lin = F.random_problem(np.random.default_rng(3024))
+    import loraine_jl_amd
+    from loraine_jl_amd.optimizer import Optimizer
+    d = loraine_jl_amd.Device(0)
+    o = Optimizer(resident=resident, device=d)
+    o.set_silent(True)
+    o.set_attribute("kit", 0)
+    o.set_attribute("datarank", -1)
+    o.load_model([[m.copy() for m in blk] for blk in A], b.copy(), 0.0, d_lin, C_lin, max_sense=False)
+    o.optimize()
+    d.close()
+    assert o.solver.status in (3, 4)
+    om = lo.make_model([[m.copy() for m in blk] for blk in A], b.copy(), 0.0, d_lin, C_lin, datarank=-1)
+    ref = lo.MySolver(om, dict(kit=0, datarank=-1, verb=0))
+    lo.solve(ref)
+    assert ref.status in (3, 4)
