@@ -818,7 +818,21 @@ const char* gemm_last_error() { return tls_gemm_error; }
 static int gemm_fail(int code, const char* why) { tls_gemm_error = why; return code; }
 
 static int gemm_impl(hipStream_t st, const GemmDesc& din);
+// hipFuncSetAttribute is per device: one process may drive several (one context per GPU)
+static bool big_tile_attr_ok() {
+  static bool done[64] = {false}, ok[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!done[dev]) {
+    ok[dev] = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * 2 * 160 * BK * 8) == hipSuccess;
+    done[dev] = true;
+  }
+  return ok[dev];
+}
+
 int gemm(hipStream_t st, const GemmDesc& din) {
+  tls_gemm_error = nullptr;            // (a stale reason must not be appended to a later, unrelated error)
   const int rc = gemm_impl(st, din);
   if (rc != LRN_OK && !tls_gemm_error) tls_gemm_error = "kernel launch failed";
   return rc;
@@ -938,9 +952,7 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     if (wgs > 0x7fffffffL) return gemm_fail(LRN_ERR_ARG, "gemm: grid too large");
     dim3 grid1((unsigned)wgs, 1, 1);
     if (big) {
-      static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5>,
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 160 * BK * 8) == hipSuccess;
-      if (!attr_ok) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
+      if (!big_tile_attr_ok()) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
       hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5>), grid1, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
     } else {
       hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4>), grid1, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
@@ -961,9 +973,7 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   if (d.C2 && (d.M != d.N || d.batch != 1 || d.ksplit != 1 || kseg)) return gemm_fail(LRN_ERR_ARG, "gemm: C2 needs a square, unbatched, unsplit product");
   if (kflat) {
     if (big) {
-      static const bool attr_ok = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5>,
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 160 * BK * 8) == hipSuccess;
-      if (!attr_ok) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
+      if (!big_tile_attr_ok()) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
       hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5>), grid, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
     } else {
       hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4>), grid, dim3(256), 2 * 2 * 128 * BK * 8, st, p);

@@ -142,24 +142,25 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   LRN_TRY(potrf_lower(s2, LS, n, n, LinvS, two ? cw2 : cw, dinfoS));
   hipLaunchKernelGGL(tril_kernel, dim3(nb2((long)n * n)), dim3(256), 0, s2, LS, n);
   if (two) LRN_HIP(c, hipEventRecord(c->evB, s2));            // LS is final
+  // the verdicts first, in the reference's order: X (prepare_W.jl:33), then S (:34) -- nothing else is queued on a failed
+  // factor (no output is touched, every pass of the host's +1e-5 I loop costs the two factorisations only), and both
+  // streams are idle when this returns
+  int h[2] = {0, 0};
+  LRN_HIP(c, hipMemcpyAsync(&h[0], dinfo, 4, hipMemcpyDeviceToHost, st));
+  LRN_HIP(c, hipMemcpyAsync(&h[1], dinfoS, 4, hipMemcpyDeviceToHost, s2));
+  LRN_HIP(c, hipStreamSynchronize(st));
+  if (two) LRN_HIP(c, hipStreamSynchronize(s2));
+  if (h[0] != 0 || h[1] != 0) {
+    *info = h[0] != 0 ? 1 : 2;
+    return LRN_OK;
+  }
+  // from here on an error return must not leave the second stream writing the shared scratch
+  struct S2Guard { hipStream_t s; bool on; ~S2Guard() { if (on) (void)hipStreamSynchronize(s); } } guard{s2, two};
   // Si = LS^-T LS^-1   (on the second stream: overlaps everything up to the end of this function)
   hipLaunchKernelGGL(eye_kernel, dim3(nb2((long)n * n)), dim3(256), 0, s2, Y2, n);
   LRN_TRY(trsm_left_lower(s2, LS, n, n, LinvS, false, Y2, n, n, two ? tw2 : tw));
   LRN_TRY(gemm_nn(s2, n, Y2, true, Y2, false, b.Si.as<double>(), GEMM_TRI_LOWER));
   hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb2((long)n * n)), dim3(256), 0, s2, b.Si.as<double>(), n);
-  // the verdicts, in the reference's order: X first (prepare_W.jl:33), then S (:34)
-  int h[2] = {0, 0};
-  LRN_HIP(c, hipMemcpyAsync(&h[0], dinfo, 4, hipMemcpyDeviceToHost, st));
-  LRN_HIP(c, hipStreamSynchronize(st));
-  if (two) LRN_HIP(c, hipEventSynchronize(c->evB));
-  else LRN_HIP(c, hipStreamSynchronize(st));
-  LRN_HIP(c, hipMemcpy(&h[1], dinfoS, 4, hipMemcpyDeviceToHost));
-  if (h[0] != 0 || h[1] != 0) {
-    if (two) LRN_HIP(c, hipStreamSynchronize(s2));            // nothing of this call may still run when the caller retries
-    *info = h[0] != 0 ? 1 : 2;
-    return LRN_OK;
-  }
-  if (two) LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
   // SVD of CC = LS' LX = U D V' by one-sided Jacobi on CC' = LX' LS: its columns are rotated by
   // U and converge to V D, so V = (columns / D) needs no accumulation of rotations -- the rounds
   // are bandwidth-bound (every round streams the whole matrix), this removes the V half of it.
@@ -210,6 +211,7 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   }
   toc(c, "prepw_gemm");
   LRN_HIP(c, hipGetLastError());
+  guard.on = false;                                           // (joined through evB above)
   b.have_W = b.have_G = true;
   b.nt_free = false;
   return LRN_OK;
@@ -346,8 +348,21 @@ __global__ void sym_inplace_kernel(double* __restrict__ M, int n) {
 // C = alpha A Bm' for a product that is symmetric in exact arithmetic, returned exactly symmetric: lower tiles + mirror on
 // the 128-tile direct-to-LDS kernel where that fills the chip, the plain product and a symmetrising pass below (at msz 800
 // the 28 lower tiles of 128 take 121 us, the full product on 64-tiles 35 us)
+// upper := lower inside the 128 x 128 diagonal tiles (GEMM_C_MIRROR mirrors the tiles below the diagonal only)
+__global__ __launch_bounds__(256) void mirror_diag_tiles_kernel(double* __restrict__ C, int n) {
+  const int t0 = blockIdx.x * 128;
+  for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+    const int i = t0 + (e & 127), j = t0 + (e >> 7);
+    if (i < n && j < n && i < j) C[(long)i + (long)j * n] = C[(long)j + (long)i * n];
+  }
+}
+
 int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha) {
-  if (n >= 1500) return gemm_nt(st, n, A, Bm, C, GEMM_TRI_LOWER | GEMM_C_MIRROR, alpha);
+  if (n >= 1500) {
+    LRN_TRY(gemm_nt(st, n, A, Bm, C, GEMM_TRI_LOWER | GEMM_C_MIRROR, alpha));
+    hipLaunchKernelGGL(mirror_diag_tiles_kernel, dim3((n + 127) / 128), dim3(256), 0, st, C, n);
+    return LRN_OK;
+  }
   LRN_TRY(gemm_nt(st, n, A, Bm, C, 0, alpha));
   hipLaunchKernelGGL(sym_inplace_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, C, n);
   return LRN_OK;

@@ -156,6 +156,29 @@ def golden_thetaG11(after_iterations=5):
           tr["objective"])
 
 
+def golden_tight(name):
+    """kit=1 solves carried to where the answer no longer depends on the path: eDIMACS 1e-8 and
+    tol_cg_min 1e-10.  A truncated-CG trajectory is not reproducible between two correct implementations (DESIGN.md
+    section 2), the optimum both stop on is: thetaG11 (C3: H_alpha, erank 1) and the truss problem tru3 (H_alpha)."""
+    import json
+    import time
+    path = os.path.join(ROOT, "tests", "golden", name + ".dat-s")
+    opts = dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-8, tol_cg_min=1e-10, verb=0)
+    t0 = time.time()
+    full = lo.MySolver(lo.model_from_sdpa(path), opts)
+    lo.solve(full)
+    tr = dict(_trace_of(full), status=int(full.status), iterations=int(full.iter), options=opts,
+              objective=lo.objective_value(full), dual_objective=lo.dual_objective_value(full),
+              cg_total=int(full.cg_iter_tot), wall_s=time.time() - t0)
+    with open(os.path.join(ROOT, "tests", "golden", "trace_%s_tight.json" % name), "w") as f:
+        json.dump(tr, f)
+    print(name, "tight:", full.iter, "iterations,", full.cg_iter_tot, "CG iterations, status", full.status, "objective %.12f" % tr["objective"],
+          "dimacs %.2e" % tr["dimacs"][-1], "%.0f s" % tr["wall_s"])
+
+
 if __name__ == "__main__":
     for name in (sys.argv[1:] or ["theta1"]):
+        if name.endswith("_tight"):
+            golden_tight(name[:-6])
+            continue
         {"theta1": golden_theta1, "maxG11": golden_maxG11, "thetaG11": golden_thetaG11}[name]()
