@@ -34,13 +34,74 @@ struct Prec {
   // diagonal (Solvers.jl:743-745); its dense Cholesky factor L_D replaces the D^-1/2 scalings
   bool has_LD = false;
   DBuf LD, linvD, wD, Cd;
+  // SMW core as an explicit inverse (option prec_inv): Sm = S + I, Ainv = (S + I)^-1 = L^-T L^-1
+  bool has_inv = false;
+  DBuf Sm, Ainv;
 };
+
+// y = alpha M x + beta z for a symmetric n x n matrix, 16 rows per workgroup, x staged in LDS (n <= 8192): one launch
+// (the solves through cholS are eight launches of 15-20 us at ksz = 801)
+__global__ __launch_bounds__(256) void symv_rows_kernel(const double* __restrict__ M, int n, const double* __restrict__ x,
+                                                        const double* __restrict__ z, double alpha, double beta,
+                                                        double* __restrict__ y) {
+  extern __shared__ double xs_[];
+  __shared__ double sh_[16 * 16];
+  const int t = threadIdx.x;
+  for (int i = t; i < n; i += 256) xs_[i] = x[i];
+  __syncthreads();
+  const int r = t & 15, g = t >> 4;
+  const int i = blockIdx.x * 16 + r;
+  double acc = 0.0;
+  if (i < n) {
+    const double* mrow = M + i;
+#pragma unroll 4
+    for (int col = g; col < n; col += 16) acc += mrow[(size_t)col * n] * xs_[col];
+  }
+  sh_[g * 16 + r] = acc;
+  __syncthreads();
+  if (t < 16) {
+    double v = 0.0;
+#pragma unroll
+    for (int gg = 0; gg < 16; ++gg) v += sh_[gg * 16 + t];
+    const int ii = blockIdx.x * 16 + t;
+    if (ii < n) y[ii] = alpha * v + (z ? beta * z[ii] : 0.0);
+  }
+}
+
+__global__ void eye_fill_kernel(double* __restrict__ V, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    V[e] = (e % n == e / n) ? 1.0 : 0.0;
+}
+
+__global__ void transpose_sq_kernel(const double* __restrict__ A, int n, double* __restrict__ B) {
+  __shared__ double tile[32][33];
+  int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int i = bx + threadIdx.x, j = by + r;
+    if (i < n && j < n) tile[r][threadIdx.x] = A[(long)i + (long)j * n];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int i = by + threadIdx.x, j = bx + r;
+    if (i < n && j < n) B[(long)i + (long)j * n] = tile[threadIdx.x][r];
+  }
+}
+
+// lower triangle -> full symmetric (in place)
+__global__ void mirror_lower_full_kernel(double* __restrict__ A, int n) {
+  long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int i = (int)(e % n), j = (int)(e / n);
+    if (i < j) A[e] = A[(long)j + (long)i * n];
+  }
+}
 
 void prec_free(lrn_ctx* c) {
   if (!c->prec) return;
   Prec* p = c->prec;
   for (DBuf* d : {&p->d, &p->ts, &p->cholS, &p->linvS, &p->cw, &p->y, &p->y2, &p->y3, &p->y4, &p->zpart, &p->E, &p->Um,
-                  &p->AU, &p->sig, &p->LD, &p->linvD, &p->wD, &p->Cd})
+                  &p->AU, &p->sig, &p->LD, &p->linvD, &p->wD, &p->Cd, &p->Sm, &p->Ainv})
     release(*d);
   delete p;
   c->prec = nullptr;
@@ -829,6 +890,14 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
     g.flags = GEMM_TRI_LOWER;
     LRN_TRY(gemm(st, g));
     hipLaunchKernelGGL(add_eye_kernel, dim3(nb(ksz)), dim3(256), 0, st, P->cholS.as<double>(), ksz);
+    // explicit (S + I)^-1 with one step of iterative refinement in the apply: three single-launch mat-vecs instead of the
+    // eight super-block launches of the two triangular solves per CG iteration (Solvers.jl:883)
+    P->has_inv = ksz <= 8192 && (c->opt.prec_inv == 1 || (c->opt.prec_inv < 0 && ksz >= 256));
+    if (P->has_inv) {
+      LRN_TRY(ensure(c, P->Sm, (size_t)ksz * ksz * 8));
+      LRN_HIP(c, hipMemcpyAsync(P->Sm.p, P->cholS.p, (size_t)ksz * ksz * 8, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(mirror_lower_full_kernel, dim3(nb((long)ksz * ksz)), dim3(256), 0, st, P->Sm.as<double>(), ksz);
+    }
     LRN_TRY(ensure(c, P->linvS, chol_linv_doubles(ksz) * 8));
     LRN_TRY(ensure(c, P->cw, (size_t)ksz * CHOL_NB * 8));
     LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, st));
@@ -837,6 +906,18 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
     int h = 0;
     LRN_TRY(copy_out(c, &h, c->info_dev.p, 4));
     if (h != 0) { if (info) *info = h; return LRN_OK; }
+    if (P->has_inv) {
+      LRN_TRY(ensure(c, P->Ainv, (size_t)ksz * ksz * 8));
+      LRN_TRY(ensure_m(c, ksz));
+      double* Li = c->m0.as<double>();
+      double* LiT = c->m1.as<double>();
+      LRN_TRY(ensure(c, P->cw, ((size_t)ksz * CHOL_NB + (size_t)CHOL_NB * ksz) * 8));
+      hipLaunchKernelGGL(eye_fill_kernel, dim3(nb((long)ksz * ksz)), dim3(256), 0, st, Li, ksz);
+      LRN_TRY(trsm_left_lower(st, P->cholS.as<double>(), ksz, ksz, P->linvS.as<double>(), false, Li, ksz, ksz,
+                              P->cw.as<double>() + (size_t)ksz * CHOL_NB));
+      hipLaunchKernelGGL(transpose_sq_kernel, dim3((ksz + 31) / 32, (ksz + 31) / 32), dim3(32, 8), 0, st, Li, ksz, LiT);
+      LRN_TRY(gemm_nt_sym(st, ksz, LiT, LiT, P->Ainv.as<double>(), 1.0));      // L^-T L^-1
+    }
     LRN_TRY(ensure(c, P->y, (size_t)(ksz + 64) * 8));
     LRN_TRY(ensure(c, P->y2, (size_t)(ksz + 64) * 8));
     LRN_TRY(ensure(c, P->y3, (size_t)(ksz + 64) * 8));
@@ -872,8 +953,20 @@ int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
     LRN_TRY(trsm_left_lower(st, P->LD.as<double>(), n, n, P->linvD.as<double>(), false, tmpv, 1, n,
                             P->wD.as<double>() + (size_t)n * CHOL_NB));
   hipLaunchKernelGGL(gemv_t_kernel, dim3(ksz), dim3(256), 0, st, P->ts.as<double>(), n, tmpv, P->y.as<double>());
-  LRN_TRY(potrs_vec(st, P->cholS.as<double>(), ksz, ksz, P->linvS.as<double>(), P->y.as<double>(), P->y2.as<double>(),
-                    P->y3.as<double>(), P->y4.as<double>()));
+  if (P->has_inv) {
+    // y2 = Ainv y; refinement: y3 = y - (S + I) y2, y2 += Ainv y3 -- the accuracy of the triangular solves, three launches
+    const unsigned g16 = (unsigned)((ksz + 15) / 16);
+    const size_t lds = (size_t)ksz * 8;
+    hipLaunchKernelGGL(symv_rows_kernel, dim3(g16), dim3(256), lds, st, P->Ainv.as<double>(), ksz, P->y.as<double>(),
+                       (const double*)nullptr, 1.0, 0.0, P->y4.as<double>());
+    hipLaunchKernelGGL(symv_rows_kernel, dim3(g16), dim3(256), lds, st, P->Sm.as<double>(), ksz, P->y4.as<double>(),
+                       P->y.as<double>(), -1.0, 1.0, P->y3.as<double>());
+    hipLaunchKernelGGL(symv_rows_kernel, dim3(g16), dim3(256), lds, st, P->Ainv.as<double>(), ksz, P->y3.as<double>(),
+                       P->y4.as<double>(), 1.0, 1.0, P->y2.as<double>());
+  } else {
+    LRN_TRY(potrs_vec(st, P->cholS.as<double>(), ksz, ksz, P->linvS.as<double>(), P->y.as<double>(), P->y2.as<double>(),
+                      P->y3.as<double>(), P->y4.as<double>()));
+  }
   const int nchunk = std::min(32, std::max(1, ksz / 32));
   const int cper = (ksz + nchunk - 1) / nchunk;
   hipLaunchKernelGGL(gemv_n_part_kernel, dim3((n + 255) / 256, nchunk), dim3(256), 0, st, P->ts.as<double>(), n, ksz,

@@ -89,6 +89,8 @@ struct LrnOptions {
   int eigmin_pair = 1;            // the two eigmin calls of a step-length search as interleaved Lanczos runs
   double jacobi_early = 3e-8;     // a sweep whose rotated column pairs were all closer to orthogonal than this ends the SVD
   bool jacobi_warm = true;
+  int prec_inv = -1;              // H_alpha: SMW core applied through an explicit inverse + one refinement step (1), the two
+                                  // triangular solves (0), auto (-1: explicit from k msz = 256 on)
   int nt_mode = 1;                // lrn_ip_prepare_w: 1 = eigen-free NT scaling (Newton-Schulz square roots of K = L_X'SL_X, Lyapunov
                                   // solve for the second-order term; falls back to the SVD when it does not converge), 0 = SVD always
   double ns_l0 = 2e-3;            // Newton-Schulz schedule: assumed lower end of spec(K)/c (slower, never wrong, when cond(K) is larger)

@@ -831,8 +831,62 @@ static bool big_tile_attr_ok() {
   return ok[dev];
 }
 
+// ---- mid-size products (round 3): a plain product whose 64 x 64 tiles do not fill the chip (msz ~ 800: 169 tiles on 256 CUs,
+// one workgroup per CU, one wave per SIMD) is bound by the latency of its global loads -- 45 us for 801^3 where the MFMAs
+// need 21.  Splitting K over 2-4 workgroups per tile puts several workgroups on every CU (their loads overlap each other's
+// MFMAs); the slabs are added in a fixed order by reduce_slabs.  Slab memory: one buffer per stream (products on different
+// streams run concurrently), grown on demand, kept for the life of the process.
+#include <map>
+#include <mutex>
+static double* split_slabs(hipStream_t st, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto& e = cache[{dev, st}];
+  if (e.second < bytes) {
+    if (e.first) { (void)hipStreamSynchronize(st); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+    if (hipMalloc(&e.first, bytes) != hipSuccess) { e.first = nullptr; return nullptr; }
+    e.second = bytes;
+  }
+  return static_cast<double*>(e.first);
+}
+
+static int auto_split_factor(const GemmDesc& d) {
+  static const int forced = getenv("LRN_GEMM_SPLIT") ? atoi(getenv("LRN_GEMM_SPLIT")) : -1;    // 0 / 1: off; k: k slabs
+  if (forced == 0 || forced == 1) return 1;
+  if (d.ksplit > 1 || d.batch != 1 || d.flags != 0 || d.C2 || d.K < 512 || d.M < 128 || d.N < 128) return 1;
+  const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+  if (t128 >= 256) return 1;                                   // the 128-tile kernels fill the chip by themselves
+  const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+  if (t64 > 400) return 1;
+  // C dense and contiguous (reduce_slabs adds flat vectors)
+  const long a = d.sCm < 0 ? -d.sCm : d.sCm, b = d.sCn < 0 ? -d.sCn : d.sCn;
+  if (!((a == 1 && b == d.M) || (b == 1 && a == d.N))) return 1;
+  if (forced > 1) return forced > 8 ? 8 : forced;
+  long ks = (640 + t64 / 2) / t64;                             // aim at ~2.5 workgroups per CU
+  if (ks < 2) ks = 2;
+  if (ks > 4) ks = 4;
+  while (ks > 2 && d.K / ks < 128) --ks;
+  return (int)ks;
+}
+
 int gemm(hipStream_t st, const GemmDesc& din) {
   tls_gemm_error = nullptr;            // (a stale reason must not be appended to a later, unrelated error)
+  const int ks = auto_split_factor(din);
+  if (ks > 1) {
+    const size_t mn = (size_t)din.M * din.N;
+    double* slabs = split_slabs(st, mn * ks * 8);
+    if (slabs) {
+      GemmDesc d2 = din;
+      d2.C = slabs; d2.sCs = (long)mn; d2.ksplit = ks; d2.beta = 0.0;
+      d2.flags |= GEMM_SMALL_TILE;
+      const int rc2 = gemm_impl(st, d2);
+      if (rc2 != LRN_OK) { if (!tls_gemm_error) tls_gemm_error = "kernel launch failed"; return rc2; }
+      return reduce_slabs(st, slabs, (long)mn, ks, din.C, (long)mn, din.beta);
+    }
+  }
   const int rc = gemm_impl(st, din);
   if (rc != LRN_OK && !tls_gemm_error) tls_gemm_error = "kernel launch failed";
   return rc;

@@ -215,18 +215,18 @@ __global__ __launch_bounds__(1024) void lz_step_kernel(const double* __restrict_
 // buffers so that nothing a workgroup still reads is overwritten inside a launch.  `do_symv` = 0: only finish step j-1
 // (last launch of a batch: the host needs alpha, beta of every step it reads).
 static constexpr int LZ_FUSED_MAX = 4096;
-__global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict__ M, int n, int nwg, int j, int do_symv,
+__global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict__ M, int n, int nwg, int j, int do_symv, int qmod,
                                                        double* __restrict__ Q3, double* __restrict__ Y2, double* __restrict__ PA2,
                                                        double* __restrict__ ab) {
   extern __shared__ double qs[];            // q_j (n doubles)
   __shared__ double sh[16 * 16 + 8];
   const int t = threadIdx.x;
-  double* qj = Q3 + (size_t)(j % 3) * n;
+  double* qj = Q3 + (size_t)(j % qmod) * n;       // qmod = 3: rotating buffers; > number of steps: every q_j is kept
   if (j == 0) {
     for (int i = t; i < n; i += 256) qs[i] = qj[i];
   } else {
-    const double* qm1 = Q3 + (size_t)((j + 2) % 3) * n;     // q_{j-1}
-    const double* qm2 = Q3 + (size_t)((j + 1) % 3) * n;     // q_{j-2}
+    const double* qm1 = Q3 + (size_t)((j - 1) % qmod) * n;  // q_{j-1}
+    const double* qm2 = Q3 + (size_t)((j > 1 ? j - 2 : 0) % qmod) * n;   // q_{j-2}
     const double* ym1 = Y2 + (size_t)((j + 1) & 1) * n;     // y_{j-1}
     const double* pa = PA2 + (size_t)((j + 1) & 1) * nwg;
     double a = 0.0;
@@ -284,6 +284,20 @@ __global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict_
     for (int off = 8; off > 0; off >>= 1) d += __shfl_down(d, off, 16);
     if (t == 0) PA2[(size_t)(j & 1) * nwg + blockIdx.x] = d;
   }
+}
+
+// steps [j0, j1) of the single-launch Lanczos recurrence with every q_j kept (Q: (j1 + 1) x n doubles, q_0 = unit start
+// vector in Q[0..n)), then the finishing launch: alpha_j, beta_j of all steps < j1 are in ab, q_{j1} in Q.  For
+// lanczos.hip (preconditioner setup); n <= LZ_FUSED_MAX.
+int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
+                   double* ab) {
+  if (n > LZ_FUSED_MAX || j1 + 1 > qcap) return LRN_ERR_ARG;
+  const int nwg = (n + 15) / 16;
+  const size_t lds = (size_t)n * 8;
+  for (int j = j0; j < j1; ++j)
+    hipLaunchKernelGGL(lz_fused_kernel, dim3(nwg), dim3(256), lds, st, M, n, nwg, j, 1, qcap, Q, Y2, PA2, ab);
+  hipLaunchKernelGGL(lz_fused_kernel, dim3(1), dim3(256), lds, st, M, n, nwg, j1, 0, qcap, Q, Y2, PA2, ab);
+  return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }
 
 // smallest eigenvalue of the symmetric tridiagonal (a_0..a_{m-1}; b_0..b_{m-2}) by bisection
@@ -420,8 +434,8 @@ static void lz_launch(LzRun& r) {
   if (r.fused) {
     const size_t lds = (size_t)r.n * 8;
     for (int j = r.m; j < r.m1; ++j)
-      hipLaunchKernelGGL(lz_fused_kernel, dim3(r.nwg), dim3(256), lds, r.st, r.M, r.n, r.nwg, j, 1, r.q, r.w, r.ypart, r.ab);
-    hipLaunchKernelGGL(lz_fused_kernel, dim3(1), dim3(256), lds, r.st, r.M, r.n, r.nwg, r.m1, 0, r.q, r.w, r.ypart, r.ab);
+      hipLaunchKernelGGL(lz_fused_kernel, dim3(r.nwg), dim3(256), lds, r.st, r.M, r.n, r.nwg, j, 1, 3, r.q, r.w, r.ypart, r.ab);
+    hipLaunchKernelGGL(lz_fused_kernel, dim3(1), dim3(256), lds, r.st, r.M, r.n, r.nwg, r.m1, 0, 3, r.q, r.w, r.ypart, r.ab);
     return;
   }
   for (int j = r.m; j < r.m1; ++j) {

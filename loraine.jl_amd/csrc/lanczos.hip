@@ -199,6 +199,78 @@ static void tri_eigvec(const std::vector<double>& a, const std::vector<double>& 
   s = x;
 }
 
+// k <= 1, n <= 4096: the same quantities from the PLAIN recurrence, one launch per step (lz_fused_steps, ipstep.hip).
+// The full re-orthogonalisation below costs seven launches per step (4.2 ms of the 6.6 ms H_alpha setup on thetaG11); one
+// extreme Ritz pair does not need it: until its Ritz value has converged no ghost copy exists, and the Ritz vector Q s of a
+// converged value is accurate although the q_j have lost their orthogonality along it (Paige).  *ok = false: not taken
+// (an invariant subspace -- W = c I at the initial point -- or no convergence): the caller runs the full version.
+static int lanczos_extremes_plain(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
+                                  double tr, int* steps_out, bool* ok) {
+  hipStream_t st = c->stream;
+  *ok = false;
+  const int mmax = std::min(n - 1, 240);
+  const int nwg = (n + 15) / 16;
+  LRN_TRY(ensure(c, c->lxbuf, ((size_t)(mmax + 2) * n + 2 * (size_t)n + 2 * (size_t)nwg + 2 * (size_t)mmax + (size_t)mmax + 64) * 8));
+  double* Q = c->lxbuf.as<double>();
+  double* Y2 = Q + (size_t)(mmax + 2) * n;
+  double* PA2 = Y2 + 2 * (size_t)n;
+  double* ab = PA2 + 2 * (size_t)nwg;
+  double* Sdev = ab + 2 * (size_t)mmax + 8;
+  hipLaunchKernelGGL(lx_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Q, n, 0u);
+  hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, Q, n, -1, Q, ab);
+  std::vector<double> a, b, hab, s_top, s_min;
+  double th_top = 0.0, th_min = 0.0;
+  int m = 0;
+  bool done = false;
+  while (!done && m < mmax) {
+    const int m1 = std::min(mmax, m + 24);
+    LRN_TRY(lz_fused_steps(st, M, n, m, m1, mmax + 2, Q, Y2, PA2, ab));
+    m = m1;
+    hab.resize(2 * (size_t)m);
+    LRN_TRY(copy_out(c, hab.data(), ab, (size_t)2 * m * 8));
+    a.resize(m); b.resize(m);
+    double scale = 0.0;
+    for (int j = 0; j < m; ++j) {
+      a[j] = hab[2 * j]; b[j] = hab[2 * j + 1];
+      scale = std::max(scale, std::fabs(a[j]) + std::fabs(b[j]));
+      if (!(b[j] > 1e-13 * scale)) return LRN_OK;                     // invariant subspace: the full version restarts
+    }
+    if (m <= k + 1) continue;
+    double worst = 0.0;
+    if (k == 1) {
+      th_top = tri_eig_by_index(a, b, m, m - 1);
+      tri_eigvec(a, b, m, th_top, s_top, 0);
+      worst = std::fabs(b[m - 1] * s_top[m - 1]) / std::max(std::fabs(th_top), 1e-300);
+    }
+    th_min = tri_eig_by_index(a, b, m, 0);
+    tri_eigvec(a, b, m, th_min, s_min, 1);
+    const double mean = std::fabs(tr - (k == 1 ? th_top : 0.0)) / (double)(n - k);
+    const double rmin = std::fabs(b[m - 1] * s_min[m - 1]);
+    done = worst <= 1e-10 && rmin <= 1e-6 * std::max(std::fabs(th_min), mean);
+    // out of steps with the wanted pair converged: what the full version does at ITS cap of 160 steps (lambda_min, which only
+    // enters tau through (lambda_min + mean) / 2, is then as settled as 240 steps make it)
+    if (!done && m >= mmax && worst <= 1e-6) done = true;
+  }
+  if (!done) return LRN_OK;
+  if (k == 1) lam_top[0] = th_top;
+  if (lam_min) *lam_min = th_min;
+  if (steps_out) *steps_out = m;
+  if (U_top && k == 1) {
+    LRN_TRY(copy_in(c, Sdev, s_top.data(), (size_t)m * 8));
+    GemmDesc g;      // u = Q[:, 0..m) s, then normalised (the q_j are only nearly orthogonal)
+    g.A = Q; g.sAm = 1; g.sAk = n;
+    g.B = Sdev; g.sBk = 1; g.sBn = m;
+    g.C = U_top; g.sCm = 1; g.sCn = n;
+    g.M = n; g.N = 1; g.K = m;
+    LRN_TRY(gemm(st, g));
+    hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, U_top, n, -1, U_top, ab);
+  }
+  LRN_HIP(c, hipGetLastError());
+  c->counts["lanczos_plain"] += 1;
+  *ok = true;
+  return LRN_OK;
+}
+
 // k largest eigenpairs + smallest eigenvalue + trace of the symmetric n x n matrix M (device).
 // lam_top[k] ascending (like F.values[n-k+1:n]); U_top (device, n x k, unit columns) may be null.
 int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
@@ -221,6 +293,20 @@ int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top,
   double tr = 0.0;
   LRN_TRY(copy_out(c, &tr, cvec, 8));
   if (trace) *trace = tr;
+  static const bool reorth_only = getenv("LRN_LX_REORTH") != nullptr;
+  if (!reorth_only && k <= 1 && n <= LZ_FUSED_LIMIT && n >= 64) {
+    bool ok = false;
+    LRN_TRY(lanczos_extremes_plain(c, M, n, k, lam_top, U_top, lam_min, tr, steps_out, &ok));
+    if (ok) return LRN_OK;
+    // (lxbuf may have been re-allocated: re-derive the workspace of the full version)
+    LRN_TRY(ensure(c, c->lxbuf, ((size_t)(mmax + 2) * n + (size_t)nchunk * n + 4 * (size_t)mmax + (size_t)mmax * (k + 1) + 128) * 8));
+    Q = c->lxbuf.as<double>();
+    w = Q + (size_t)(mmax + 1) * n;
+    ypart = w + n;
+    ab = ypart + (size_t)nchunk * n;
+    cvec = ab + 2 * (size_t)mmax + 8;
+    Sdev = cvec + mmax + 8;
+  }
   hipLaunchKernelGGL(lx_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Q, n, 0u);
   hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, Q, n, -1, Q, ab);
   std::vector<double> a, b, hab;

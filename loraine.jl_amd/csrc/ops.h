@@ -21,4 +21,8 @@ int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double
 // k largest eigenpairs (ascending), smallest eigenvalue and trace of a dense symmetric matrix
 int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
                      double* trace, int* steps_out);
+// single-launch Lanczos steps [j0, j1) keeping every q_j (ipstep.hip); PA2: 2 * ceil(n / 16) doubles, Y2: 2 n doubles
+int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
+                   double* ab);
+static constexpr int LZ_FUSED_LIMIT = 4096;
 }  // namespace lrn
