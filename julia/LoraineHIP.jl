@@ -240,7 +240,29 @@ function stats(ctx::Ctx, nlmi::Int)
     return out
 end
 
-# ---- multi-GPU exchange (one process per GPU, e.g. MPI.jl ranks): SURVEY.md 8e -----------------
+# ---- multi-GPU: one process per GPU, the exchange INSIDE the library (csrc/comm.hip) --------------
+# `predictor` / `corrector` stay as they are: after `comm_init!` the calls above (`makeBBBB!`, `cg`, `MyA_hip`) assemble
+# this rank's share, agree on the path, check every rank's outcome and exchange over RCCL on the library's stream.
+#   using MPI; MPI.Init(); comm = MPI.COMM_WORLD; r = MPI.Comm_rank(comm); P = MPI.Comm_size(comm)
+#   ctx = Ctx(r % ngpus_per_node)
+#   id = r == 0 ? comm_unique_id() : Vector{UInt8}(undef, 128); MPI.Bcast!(id, 0, comm)
+#   comm_init!(ctx, id, r, P)
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    rc = ccall((:lrn_comm_unique_id, LIB), Cint, (Ptr{UInt8},), id)
+    rc == 0 || error("lrn_comm_unique_id failed ($rc)")
+    return id
+end
+comm_init!(ctx::Ctx, id::Vector{UInt8}, rank::Int, world::Int) =
+    check(ctx, ccall((:lrn_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), ctx.h, id, rank, world), "lrn_comm_init")
+comm_destroy!(ctx::Ctx) = check(ctx, ccall((:lrn_comm_destroy, LIB), Cint, (Ptr{Cvoid},), ctx.h), "lrn_comm_destroy")
+# replicated scalars of the host loop (op: 0 sum, 1 min, 2 max), e.g. a sanity check that all ranks hold the same mu
+function comm_allreduce!(ctx::Ctx, v::Vector{Float64}, op::Int = 0)
+    check(ctx, ccall((:lrn_comm_allreduce, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint), ctx.h, v, length(v), op), "lrn_comm_allreduce")
+    return v
+end
+
+# ---- the pieces of the exchange, for a host that brings its own collectives (ROCm-aware MPI): SURVEY.md 8e ----
 set_shard!(ctx::Ctx, rank::Int, world::Int) =
     check(ctx, ccall((:lrn_set_shard, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), ctx.h, rank, world), "lrn_set_shard")
 shard_doubles(ctx::Ctx) = ccall((:lrn_schur_shard_doubles, LIB), Int64, (Ptr{Cvoid},), ctx.h)
