@@ -466,7 +466,9 @@ static int dbg_factor(lrn_ctx* c, int n, const double* A, DBuf& dA, DBuf& dI, in
   LRN_TRY(ensure(c, c->info_dev, 64));
   LRN_TRY(copy_in(c, dA.p, A, (size_t)n * n * 8));
   LRN_HIP(c, hipMemsetAsync(c->info_dev.p, 0, 4, c->stream));
+  tic(c);
   LRN_TRY(potrf_lower(c->stream, dA.as<double>(), n, n, dI.as<double>(), dW.as<double>(), c->info_dev.as<int>()));
+  toc(c, "dbg_potrf");
   int h = 0;
   LRN_TRY(copy_out(c, &h, c->info_dev.p, 4));
   if (info) *info = h;

@@ -300,7 +300,10 @@ __global__ __launch_bounds__(256) void jb_rotate_kernel(const double* __restrict
     // k2 equals my k1 -- halves the dependent FP64 chain of a step
     double c1, s1, c2, s2;
     rotated |= jrot(al, be, ga, tol, &c2, &s2);
-    big |= ga * ga > big2 * al * be;
+    // "above the early-stop level": the columns were further from orthogonal than `early`, OR the rotation that was applied
+    // has a large angle -- inside a cluster of singular values (relative width < early) the cosines stay below the
+    // level while the angles are O(1), and such rotations re-perturb pairs annihilated earlier to first order
+    big |= ga * ga > big2 * al * be || s2 * s2 > 1e-4;
     c1 = __shfl(c2, src, 64);
     s1 = __shfl(s2, src, 64);
     // 2x2 block (pair k1 rows, pair k2 columns):  B' = J1' B J2
@@ -533,7 +536,10 @@ __global__ __launch_bounds__(1024) void jb2_rotate_kernel(const double* __restri
     }
     double c1, s1, c2, s2;
     rotated |= jrot(al, be, ga, tol, &c2, &s2);
-    big |= ga * ga > big2 * al * be;
+    // "above the early-stop level": the columns were further from orthogonal than `early`, OR the rotation that was applied
+    // has a large angle -- inside a cluster of singular values (relative width < early) the cosines stay below the
+    // level while the angles are O(1), and such rotations re-perturb pairs annihilated earlier to first order
+    big |= ga * ga > big2 * al * be || s2 * s2 > 1e-4;
     c1 = __shfl(c2, src, 64);
     s1 = __shfl(s2, src, 64);
     double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
