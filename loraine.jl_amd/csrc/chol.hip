@@ -15,6 +15,8 @@
 //    beyond 1e12, where inv(L_kk) costs the digits LAPACK's backward-stable solves keep);
 //    the off-diagonal panels are streamed once per block (bandwidth-bound, coalesced).
 //    The `Linv` arguments of the entry points are kept for the callers' workspaces but unused.
+#include <cstdlib>
+
 #include "lrn_common.h"
 #include "chol.h"
 
@@ -134,6 +136,67 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   }
 }
 
+// The same panel solve with EIGHT lanes per row (round 3).  One thread per row walks 2016 dependent FMA + LDS-read pairs
+// (30 us per panel, n / 64 panels per factorisation: a third of the factorisation of the C2 / C3 / truss matrices).  Here
+// lane (row, b) owns the 8 columns [8 b, 8 b + 8) of its row: in stage s the lanes with b = s solve their 8 x 8
+// triangular block and publish x through LDS, the lanes with b > s subtract its contribution from their columns -- a
+// critical path of 8 x (36 + 64) pairs instead of 2016.  32 rows per workgroup.
+__global__ __launch_bounds__(256) void potrf_panel8_kernel(double* __restrict__ A21, int ld, int rem,
+                                                           const double* __restrict__ Lkk, double* __restrict__ W,
+                                                           const int* __restrict__ info) {
+  __shared__ double l[NB][NB + 1];
+  __shared__ double rinv[NB];
+  __shared__ double xs[32][NB + 1];
+  if (*info != 0) return;
+  const int t = threadIdx.x;
+  for (int e = t; e < NB * NB; e += 256) {
+    int i = e % NB, j = e / NB;
+    l[i][j] = i >= j ? Lkk[(long)i + (long)j * ld] : 0.0;
+  }
+  __syncthreads();
+  if (t < NB) rinv[t] = 1.0 / l[t][t];
+  const int rl = t >> 3, b = t & 7;                 // row of the workgroup, block of 8 columns
+  const int row = blockIdx.x * 32 + rl;
+  const bool live = row < rem;
+  double a[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a[c] = live ? A21[(long)row + (long)(8 * b + c) * ld] : 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (b == s) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        double v = a[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= a[k] * l[8 * s + c][8 * s + k];
+        v *= rinv[8 * s + c];
+        a[c] = v;
+        xs[rl][8 * s + c] = v;
+      }
+    }
+    __syncthreads();
+    if (b > s) {
+      double x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = xs[rl][8 * s + k];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        double v = a[c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v -= x[k] * l[8 * b + c][8 * s + k];
+        a[c] = v;
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    A21[(long)row + (long)(8 * b + c) * ld] = a[c];
+    W[(long)row + (long)(8 * b + c) * rem] = a[c];
+  }
+}
+
 // Diagonal step of the matrix solves: X_b = L_kk^-1 B_b (trans = 0) or L_kk^-T B_b (trans = 1) for the
 // block rows [k0, k0 + nb) of B (ldb), one thread per right-hand side; result in place and in
 // tmp (NB x nrhs, ld NB).
@@ -226,8 +289,13 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
     int rem = n - k0 - nb;
     if (rem <= 0) break;
     // panel: Wk = A21 * Lkk^-T      (rem x nb), by substitution
-    hipLaunchKernelGGL(potrf_panel_kernel, dim3((rem + 255) / 256), dim3(256), 0, st,
-                       A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
+    static const bool one_lane = getenv("LRN_POTRF_PANEL1") != nullptr;
+    if (one_lane || nb < NB)
+      hipLaunchKernelGGL(potrf_panel_kernel, dim3((rem + 255) / 256), dim3(256), 0, st,
+                         A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
+    else
+      hipLaunchKernelGGL(potrf_panel8_kernel, dim3((rem + 31) / 32), dim3(256), 0, st,
+                         A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
     int rc;
     // trailing: A22 -= Wk Wk^T (lower tiles)
     GemmDesc u;
