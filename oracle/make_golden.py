@@ -163,7 +163,8 @@ def golden_tight(name):
     import json
     import time
     path = os.path.join(ROOT, "tests", "golden", name + ".dat-s")
-    opts = dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-8, tol_cg_min=1e-10, verb=0)
+    opts = dict(kit=1, preconditioner=1, erank=1, eDIMACS=float(os.environ.get("TIGHT_EDIMACS", "1e-8")),
+                tol_cg_min=float(os.environ.get("TIGHT_TOL_CG_MIN", "1e-10")), verb=int(os.environ.get("TIGHT_VERB", "0")))
     t0 = time.time()
     full = lo.MySolver(lo.model_from_sdpa(path), opts)
     lo.solve(full)
