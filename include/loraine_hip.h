@@ -77,7 +77,14 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * "jacobi_cross" (1: cross-pair rotations only after round 0), "jacobi_early" (relative level below which a sweep's
  * rotations make it the last one; 0 = always run the confirming sweep), "eigmin_pair" (1: the two
  * smallest-eigenvalue searches of a step-length computation as interleaved Lanczos runs on two streams),
- * "prepw_streams" (1: lrn_prepare_w runs the S side and the Gi solve on a second stream), "reset_timing". */
+ * "prepw_streams" (1: lrn_prepare_w runs the S side and the Gi solve on a second stream),
+ * "nt_mode" (lrn_ip_prepare_w: 1 = NT scaling without singular vectors -- Newton-Schulz square roots of K = L_X'SL_X,
+ * Lyapunov solve for the second-order term, SVD route as fallback --, 0 = the reference's SVD route always; lrn_prepare_w
+ * with output pointers always takes the SVD route), "ns_l0" (assumed lower end of spec(K)/c of the Newton-Schulz schedule),
+ * "ns_maxit", "ns_dual" (-1 auto / 1 / 0: transposed twins of the products from the GEMM epilogue or a transpose pass),
+ * "lyap_tol", "lyap_maxit" (relative residual / step limit of the Lyapunov CG),
+ * "prec_inv" (H_alpha: -1 auto / 1 / 0: SMW core through an explicit inverse + one refinement step, or two triangular solves),
+ * "shard_passes" (multi-GPU, 1: the passes over dense constraint data in AA*vec(.) / mat(AA'x) split by rank), "reset_timing". */
 int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
 /* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */
 int lrn_set_shard(lrn_ctx* ctx, int rank, int world);

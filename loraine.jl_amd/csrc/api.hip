@@ -58,6 +58,8 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->lzbuf2);
   release(c->lxbuf);
   release(c->ezbuf);
+  release(c->commvec);
+  release(c->commmat);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   if (c->evA) (void)hipEventDestroy(c->evA);
@@ -104,6 +106,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "jacobi_warm")) c->opt.jacobi_warm = value != 0.0;
   else if (!strcmp(key, "nt_mode")) c->opt.nt_mode = (int)value;
   else if (!strcmp(key, "prec_inv")) c->opt.prec_inv = (int)value;
+  else if (!strcmp(key, "shard_passes")) c->opt.shard_passes = (int)value;
   else if (!strcmp(key, "ns_l0")) c->opt.ns_l0 = value;
   else if (!strcmp(key, "ns_maxit")) c->opt.ns_maxit = (int)value;
   else if (!strcmp(key, "ns_dual")) c->opt.ns_dual = (int)value;

@@ -89,6 +89,7 @@ struct LrnOptions {
   int eigmin_pair = 1;            // the two eigmin calls of a step-length search as interleaved Lanczos runs
   double jacobi_early = 3e-8;     // a sweep whose rotated column pairs were all closer to orthogonal than this ends the SVD
   bool jacobi_warm = true;
+  int shard_passes = 1;           // multi-GPU: split AA*vec(.) and mat(AA'x) over dense constraints by rank (+ one all-reduce)
   int prec_inv = -1;              // H_alpha: SMW core applied through an explicit inverse + one refinement step (1), the two
                                   // triangular solves (0), auto (-1: explicit from k msz = 256 on)
   int nt_mode = 1;                // lrn_ip_prepare_w: 1 = eigen-free NT scaling (Newton-Schulz square roots of K = L_X'SL_X, Lyapunov
@@ -151,6 +152,7 @@ struct lrn_ctx {
   hipEvent_t evC = nullptr, evD = nullptr;
   // generic scratch
   lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lzbuf2, lxbuf, ezbuf;
+  lrn::DBuf commvec, commmat;   // multi-GPU: partial results of the sharded passes over dense constraint data
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
   // multi-GPU communicator (comm.hip; lrn_comm_init / lrn_comm_init_host)

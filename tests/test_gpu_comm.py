@@ -77,3 +77,14 @@ def test_two_ranks_on_one_gpu_solve_through_the_library_communicator(tmp_path):
     assert r[0]["lowrank_cg"]["status"] == 1 and r[0]["lowrank_cg"]["obj"] == r[1]["lowrank_cg"]["obj"]
     assert r[0]["dense"]["status"] == 1 and r[0]["dense"]["obj"] == r[1]["dense"]["obj"]
     assert r[0]["dense"]["iters"] == r[1]["dense"]["iters"]
+    # the same dense problem on ONE rank (here, in the parent): the two-rank run -- column split of the assembly, the passes
+    # over the constraint data split by constraints, both summed by all-reduces -- must land on the same iterates
+    import loraine_jl_amd
+    from loraine_jl_amd.synthetic import synthetic_dense_solver
+    dev = loraine_jl_amd.Device(0)
+    dev.set_option("schur_chol", 1)
+    solver, ha = synthetic_dense_solver(dev, 96, 160, seed=11, options=dict(kit=0, verb=0))
+    solver.solve(ha)
+    dev.close()
+    assert solver.status == 1 and solver.iter == r[0]["dense"]["iters"]
+    assert r[0]["dense"]["obj"] == pytest.approx(float(solver.primal_obj), rel=1e-9)
