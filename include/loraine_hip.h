@@ -171,6 +171,10 @@ int lrn_ip_aa_x(lrn_ctx* ctx, double* out);
 int lrn_ip_residual_d(lrn_ctx* ctx, const double* y);
 /* out = sum_i AA[i]*vec(W(Rd+S)W)   (makeRHS without Rp, src/makeBBBB.jl:221-228) */
 int lrn_ip_rhs_pred(lrn_ctx* ctx, double* out);
+/* lrn_ip_aa_x and lrn_ip_rhs_pred in one call: aax_out = sum_i AA[i]*vec(X[i]) (for Rp, src/predictor_corrector.jl:12) and
+ * out as lrn_ip_rhs_pred (src/makeBBBB.jl:221-228), with dense constraint data read ONCE for both -- on the 128 GB
+ * instance every pass over it costs 25 ms.  The residual Rp is not needed between :12 and :44. */
+int lrn_ip_rhs_pred2(lrn_ctx* ctx, double* aax_out, double* out);
 /* out = sum_i AA[i]*my_kron(G,G, G'RdG + D - sigma_mu./D - RNT)   (src/predictor_corrector.jl:186) */
 int lrn_ip_rhs_corr(lrn_ctx* ctx, double sigma_mu, double* out);
 /* delS, delX and the per-block step lengths alpha[nlmi], beta[nlmi]

@@ -208,6 +208,11 @@ function rhs_pred(ctx::Ctx, n::Int)                                  # makeRHS w
     check(ctx, ccall((:lrn_ip_rhs_pred, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.h, h), "lrn_ip_rhs_pred")
     return h
 end
+function rhs_pred2(ctx::Ctx, n::Int)                                 # AA*vec(X) (:12) and makeRHS (:44): dense data read once
+    aax = zeros(n); h = zeros(n)
+    check(ctx, ccall((:lrn_ip_rhs_pred2, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.h, aax, h), "lrn_ip_rhs_pred2")
+    return aax, h
+end
 function rhs_corr(ctx::Ctx, n::Int, sigma_mu::Float64)               # predictor_corrector.jl:186
     h = Vector{Float64}(undef, n)
     check(ctx, ccall((:lrn_ip_rhs_corr, LIB), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}), ctx.h, sigma_mu, h), "lrn_ip_rhs_corr")

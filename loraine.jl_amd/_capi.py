@@ -67,6 +67,7 @@ SIGNATURES = {
     "lrn_ip_aa_x": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_ip_residual_d": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_ip_rhs_pred": (C.c_int, [c_ctx, C.c_void_p]),
+    "lrn_ip_rhs_pred2": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     "lrn_ip_rhs_corr": (C.c_int, [c_ctx, C.c_double, C.c_void_p]),
     "lrn_ip_find_step": (C.c_int, [c_ctx, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrn_ip_update": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

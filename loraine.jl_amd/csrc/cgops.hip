@@ -464,6 +464,42 @@ int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
   return LRN_OK;
 }
 
+// out1[sigma[p]] -= <Adense[p], Z1>, out2[sigma[p]] -= <Adense[p], Z2>: ONE pass over the dense constraint data for two
+// products (C4: 128 GB per pass)
+__global__ __launch_bounds__(256) void aa_dense_dot2_kernel(const double* __restrict__ Ad, long mm, const double* __restrict__ Z1,
+                                                            const double* __restrict__ Z2, const int* __restrict__ sigma,
+                                                            double* __restrict__ out1, double* __restrict__ out2) {
+  __shared__ double sh[8];
+  const double* a = Ad + (long)blockIdx.x * mm;
+  double s1 = 0.0, s2 = 0.0;
+  for (long q = threadIdx.x; q < mm; q += 256) { const double v = a[q]; s1 += v * Z1[q]; s2 += v * Z2[q]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out1[sigma[blockIdx.x]] -= sh[0] + sh[1] + sh[2] + sh[3];
+    out2[sigma[blockIdx.x]] -= sh[4] + sh[5] + sh[6] + sh[7];
+  }
+}
+
+// y1 += AA vec(Z1), y2 += AA vec(Z2) with the dense constraint data read once
+int aa_times2(lrn_ctx* c, LmiBlock& b, const double* Z1, double* y1, const double* Z2, double* y2) {
+  if (b.nd <= 0 || dense_passes_sharded(c, b)) {      // (the sharded pass is 1/world of the data already)
+    LRN_TRY(aa_times(c, b, Z1, y1));
+    return aa_times(c, b, Z2, y2);
+  }
+  if (b.npos_nz > b.nd) {
+    for (int h = 0; h < 2; ++h)
+      hipLaunchKernelGGL(aa_times_kernel, dim3((b.npos_nz - b.nd + 3) / 4), dim3(256), 0, c->stream, b.ent_ptr.as<long>(),
+                         b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(), h ? Z2 : Z1, b.msz, b.nd, b.npos_nz,
+                         b.sigma_d.as<int>(), h ? y2 : y1);
+  }
+  hipLaunchKernelGGL(aa_dense_dot2_kernel, dim3(b.nd), dim3(256), 0, c->stream, b.Adense.as<double>(), (long)b.msz * b.msz,
+                     Z1, Z2, b.sigma_d.as<int>(), y1, y2);
+  return LRN_OK;
+}
+
 // M = mat(AA' x)  (symmetrised msz x msz, kron_etc.jl:13-18)
 int aat_to_mat(lrn_ctx* c, LmiBlock& b, const double* x, double* M) {
   const int m = b.msz;

@@ -869,6 +869,25 @@ extern "C" int lrn_ip_rhs_pred(lrn_ctx* c, double* out) {
   return copy_out(c, out, c->v1.p, (size_t)n * 8);
 }
 
+extern "C" int lrn_ip_rhs_pred2(lrn_ctx* c, double* aax_out, double* out) {
+  if (!c || !aax_out || !out) return LRN_ERR_ARG;
+  LRN_HIP(c, hipSetDevice(c->device));
+  const int n = c->nvar;
+  LRN_TRY(ensure(c, c->v2, (size_t)(n + 64) * 8));
+  LRN_HIP(c, hipMemsetAsync(c->v1.p, 0, (size_t)n * 8, c->stream));
+  LRN_HIP(c, hipMemsetAsync(c->v2.p, 0, (size_t)n * 8, c->stream));
+  for (auto& b : c->lmi) {
+    LRN_TRY(ensure_resident(c, b));
+    const long mm_ = (long)b.msz * b.msz;
+    hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t0.as<double>(), 1.0, b.Rd.as<double>(),
+                       1.0, b.S.as<double>(), 0.0, (const double*)nullptr, mm_);
+    LRN_TRY(wmw(c, b, b.t0.as<double>(), b.t1.as<double>(), b.t2.as<double>()));
+    LRN_TRY(aa_times2(c, b, b.X.as<double>(), c->v2.as<double>(), b.t2.as<double>(), c->v1.as<double>()));
+  }
+  LRN_TRY(copy_out(c, aax_out, c->v2.p, (size_t)n * 8));
+  return copy_out(c, out, c->v1.p, (size_t)n * 8);
+}
+
 extern "C" int lrn_ip_rhs_corr(lrn_ctx* c, double sigma_mu, double* out) {
   if (!c || !out) return LRN_ERR_ARG;
   LRN_HIP(c, hipSetDevice(c->device));

@@ -5,6 +5,7 @@ namespace lrn {
 int ensure_m(lrn_ctx* c, int m);                                            // c->m0..m2 >= msz^2
 int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z);          // Z = W M W (M symmetric)
 int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y);          // y += AA vec(Z)
+int aa_times2(lrn_ctx* c, LmiBlock& b, const double* Z1, double* y1, const double* Z2, double* y2);   // both, one pass over dense data
 int aat_to_mat(lrn_ctx* c, LmiBlock& b, const double* x, double* M);        // M = mat(AA' x)
 int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info);                    // NT scaling from b.X, b.S (SVD route)
 // eigen-free NT scaling from b.X, b.S: W, Si, the Cholesky factors and K^(+-1/2); *converged = false: nothing usable, take

@@ -416,6 +416,12 @@ class Device:
     def ip_rhs_pred(self):
         return self._vec_out(self.lib.lrn_ip_rhs_pred, "lrn_ip_rhs_pred")
 
+    def ip_rhs_pred2(self):
+        """(AA*vec(X), makeRHS term) with dense constraint data read once."""
+        aax = np.zeros(self.nvar); out = np.zeros(self.nvar)
+        self._chk(self.lib.lrn_ip_rhs_pred2(self.h, ptr(aax), ptr(out)), "lrn_ip_rhs_pred2")
+        return aax, out
+
     def ip_rhs_corr(self, sigma_mu):
         return self._vec_out(self.lib.lrn_ip_rhs_corr, "lrn_ip_rhs_corr", C.c_double(sigma_mu))
 

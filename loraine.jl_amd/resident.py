@@ -74,21 +74,22 @@ class ResidentSolver(MySolver):
         self.predict = True
         Rp = m.b.copy()
         if m.nlmi > 0:
-            Rp -= dev.ip_aa_x()                                              # [GPU] AA*vec(X)
             dev.ip_residual_d(self.y)                                        # [GPU] Rd
         if m.nlin > 0:
             Rp -= m.C_lin @ self.X_lin
             self.Rd_lin = m.d_lin - self.S_lin - m.C_lin.T @ self.y
             dev.set_lin(self.X_lin, self.S_lin_inv)
-        self.Rp = Rp
         if self.kit == 0:
             mode = -1 if (self.datarank == -1 and m.nlmi > 0) else 0
-            dev.schur_assemble(mode)                                         # [GPU]
-            if self.dist is not None:
-                self.dist.allgather(dev)                                     # multi-GPU: column blocks -> all ranks
-        h = self.Rp.copy()
+            dev.schur_assemble(mode)                                         # [GPU] (+ the exchange when sharded)
+        rhs = 0.0
         if m.nlmi > 0:
-            h += dev.ip_rhs_pred()                                           # [GPU] makeRHS
+            # Rp = b - AA*vec(X) (:12) is not used before makeRHS (:44): both products in ONE pass over the constraint
+            # data (dense data: 128 GB per pass at C4)
+            aax, rhs = dev.ip_rhs_pred2()                                    # [GPU] AA*vec(X), makeRHS
+            Rp -= aax
+        self.Rp = Rp
+        h = self.Rp + rhs
         if m.nlin > 0:
             h = h + m.C_lin @ ((self.X_lin * self.Si_lin) * self.Rd_lin + self.X_lin)
         if self.kit == 0:
