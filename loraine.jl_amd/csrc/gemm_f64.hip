@@ -1103,6 +1103,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) 
     LRN_MFMA(c4); LRN_MFMA(c5); LRN_MFMA(c6); LRN_MFMA(c7);
   }
 #undef LRN_MFMA
+  LRN_MFMA_DRAIN();            // (the asm MFMAs are invisible to the hazard recogniser: retire them before the VALU reads)
   v4f64 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
   if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];
 }
