@@ -145,7 +145,10 @@ def test_c3_thetaG11_whole_solve_against_the_oracle_trace():
     assert abs(o.solver.cg_iter_tot - tr["cg_total"]) <= 0.15 * tr["cg_total"]
 
 
-@pytest.mark.parametrize("name,suffix,edimacs", [("thetaG11", "tight", 1e-6), ("tru3", "tight", 1e-6), ("thetaG11", "tight7", 1e-7)])
+# (trace_thetaG11_tight7.json, eDIMACS 1e-7 / tol_cg_min 1e-9, is recorded evidence only: 8e-13 relative when it was run with
+# tools/c3_tight.py, but that close to the breakdown of H_alpha a CG call can take its 10000 iterations and the solve
+# anything between 5 s and 4 minutes depending on rounding -- not a test)
+@pytest.mark.parametrize("name,suffix,edimacs", [("thetaG11", "tight", 1e-6), ("tru3", "tight", 1e-6)])
 def test_kit1_solves_agree_where_both_sit_on_the_optimum(name, suffix, edimacs):
     """VERDICT r2 item 4(ii).  A truncated-CG trajectory is not reproducible between two correct implementations (DESIGN.md
     section 2), so C3's objectives at its stock tolerance (eDIMACS 1e-5) agree to 3e-7 only.  One decade further in both

@@ -36,18 +36,21 @@ def test_newton_schulz_is_stable_only_with_literal_products():
     c = min(np.abs(K).sum(0).max(), np.linalg.norm(K))
     res = {}
     np.seterr(all="ignore")
-    for mode in ("literal", "transposed"):
+    for mode in ("literal", "transposed", "P-mirrored"):
         Y, Z, ell, hist = K / c, np.eye(n), np.sqrt(2e-3), []
         for _ in range(30):
-            Pm = Z @ Y if mode == "literal" else Z @ Y.T
+            Pm = Z @ Y if mode != "transposed" else Z @ Y.T
+            if mode == "P-mirrored":                        # what the device does: lower tiles of P + mirror, T symmetric,
+                Pm = np.tril(Pm) + np.tril(Pm, -1).T        # Y T and T Z literal
             hist.append(np.linalg.norm(np.eye(n) - Pm))
             if 1 - ell > 1e-9:
                 a = np.sqrt(3 / (1 + ell + ell * ell)); ell = .5 * a * ell * (3 - a * a * ell * ell)
             else:
                 a = 1.0
             T = a * (3 * np.eye(n) - a * a * Pm) / 2
-            Y, Z = (Y @ T, T @ Z) if mode == "literal" else (Y @ T.T, T @ Z.T)
+            Y, Z = (Y @ T, T @ Z) if mode != "transposed" else (Y @ T.T, T @ Z.T)
         res[mode] = hist
     assert max(res["literal"][14:]) < 1e-11
+    assert max(res["P-mirrored"][14:]) < 1e-10
     grown = np.nanmax(res["transposed"][12:]) if np.isfinite(res["transposed"][12:]).any() else np.inf
     assert not np.isfinite(res["transposed"][-1]) or grown > 1e3 * min(res["transposed"])       # (it overflows to NaN)
