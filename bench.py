@@ -343,13 +343,20 @@ def main():
             # Schur entry; units = lower-triangle entries of the owned columns (position space)
             entries = float(sum(nvar - int(j) for j in own))
             alg_flops_launch = entries * msz * (msz + 1.0) / launches_per_step
-            if chol_path and world > 1:
+            strip = chol_path and dev.count("gemm3s") > 0
+            if chol_path:
                 # every rank forms ALL entries over ITS columns of the matrix variable: its share of the packed
-                # length (timed as gemm3 over all its launches)
-                alg_flops_launch = (nvar * (nvar + 1.0) / 2.0) * msz * (msz + 1.0) * dev.timing("gemm3_share") / launches_per_step
-            kname = ("gemm_f64_kseg_lds_kernel<true> GEMM3' H[j,i] = <L'A_jL, L'A_iL> (packed lower tiles, split-K)"
+                # length (1 on one GPU).  With nvar % 128 in (0, 32] the last 128 + nvar % 128 rows of H are a launch
+                # of their own ("gemm3s", 128 x 160 tiles): the launch priced here holds the leading rows
+                lead = nvar - 128 - nvar % 128 if strip else nvar
+                alg_flops_launch = (lead * (lead + 1.0) / 2.0) * msz * (msz + 1.0) * dev.timing("gemm3_share") / launches_per_step
+            kname = (("gemm_f64_kseg_lds_kernel<true, 4, 4> GEMM3' H[j,i] = <L'A_jL, L'A_iL>, rows j < %d (packed lower tiles, "
+                      "split-K; the last %d rows: a second launch of 128 x 160 tiles, phase gemm3s)" % (lead, nvar - lead))
+                     if strip else
+                     "gemm_f64_kseg_lds_kernel<true> GEMM3' H[j,i] = <L'A_jL, L'A_iL> (packed lower tiles, split-K)"
                      if chol_path else "gemm_f64_kseg_lds_kernel<false> GEMM3 H[j,i] = <A_j, W A_i W> (lower tiles, split-K)")
-            kpat = "gemm_f64_kseg_lds_kernel<true" if chol_path else "gemm_f64_kseg_lds_kernel<false"     # (<FLAT, tile blocks>)
+            kpat = (("gemm_f64_kseg_lds_kernel<true, 4, 4>" if strip else "gemm_f64_kseg_lds_kernel<true") if chol_path
+                    else "gemm_f64_kseg_lds_kernel<false")     # (<FLAT, tile blocks>)
         elif dom == "gemm1":
             units_per_launch = (nvar if chol_path else nown) / launches_per_step      # constraint matrices per launch
             alg_flops_launch = (2.0 / 3.0 if chol_path else (1.0 if via_l else 2.0)) * msz ** 3 * units_per_launch
@@ -369,7 +376,7 @@ def main():
             kpat = "gemm_f64_lds_kernel<true>"
         achieved = alg_flops_launch / (t1 * 1e-3) / 1e12
         phases = {k: dev.timing(k) / args.steps
-                  for k in ("wchol", "gemm1", "gemm2", "gemm3", "reduce3", "assemble", "exchange", "factor", "solve")}
+                  for k in ("wchol", "gemm1", "gemm2", "gemm3", "gemm3s", "reduce3", "assemble", "exchange", "factor", "solve")}
         cols = sharding.column_range(msz, nvar, rank, world) if chol_path else None
         return {"rank": rank, "chol_path": chol_path, "via_l": via_l, "kpat": kpat, "phases": phases,
                 "columns": list(cols) if cols else None,

@@ -93,6 +93,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "gemm_no_skip")) c->opt.gemm_no_skip = (int)value;
   else if (!strcmp(key, "gemm3_sched")) c->opt.gemm3_sched = (int)value;
   else if (!strcmp(key, "gemm3_tile")) c->opt.gemm3_tile = (int)value;
+  else if (!strcmp(key, "gemm3_strip")) c->opt.gemm3_strip = (int)value;
   else if (!strcmp(key, "gemm3_stagger")) c->opt.gemm3_stagger = (int)value;
   else if (!strcmp(key, "jacobi_wgs")) c->opt.jacobi_wgs = (int)value;
   else if (!strcmp(key, "jacobi_block")) c->opt.jacobi_block = (int)value;

@@ -79,6 +79,7 @@ struct LrnOptions {
   int gemm3_ksplit = 0;           // split-K factor of GEMM3 / GEMM3' (0 = auto)
   int gemm_no_skip = 0;           // measurement only: GEMM1'/2'/3' compute every 16x16 block (GEMM_NO_SKIP)
   int gemm3_sched = 1;            // 1: one launch, regular tiles of every split first, short tiles last; 0: two launches
+  int gemm3_strip = 1;            // GEMM3': nd % 128 in (0, 32] -> last tile row of height 128 + nd % 128 (second launch)
   int gemm3_tile = 0;             // workgroup tile of GEMM3': 0 auto, 128, 160
   int gemm3_stagger = 0;          // K-walk stagger of GEMM3' in chunks of 16 (GemmDesc::kstagger)
   int jacobi_inner = 0;           // sweeps over the pair's Gram matrix per round (more did not cut the outer sweeps: 1)

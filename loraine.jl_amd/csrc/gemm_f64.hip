@@ -42,6 +42,7 @@ struct GemmParams {
   // tile_list for split 0, 1, ... and then [x q2, (x+1) q2) of tile_list2 for split 0, 1, ...
   const int2* tile_list2;
   int n1, n2;                    // list lengths (multiples of 8); n2 < 0: the plain (tile, split) grid
+  int m_org = 0, n_org = 0;      // K-contiguous kernels: origin of tile (0, 0) (a sub-range of C tiled on its own)
 };
 
 #define MFMA_F64_ROW(lane, r) (((lane) >> 4) + 4 * (r))
@@ -522,11 +523,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
 // lane; two images of 160 x 16 doubles, double-buffered = 80 KB per workgroup -- two workgroups fill the CU's 160 KB of
 // LDS exactly).  The larger tile moves 0.8 of the panel bytes per flop, spends 100 instead of 64 MFMAs per wave between
 // barriers, and nvar = 4000 = 25 x 160 has no edge tiles at all.
-template <bool FLAT, int TB>
+// TBM x TBN = 4 x 5: the 128 x 160 tiles of a last tile row of height 160 (nvar = 4000 = 30 x 128 + 160: no edge tiles).
+template <bool FLAT, int TBM, int TBN>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p) {
-  constexpr int BM = 32 * TB, BN = 32 * TB, TM = TB, TN = TB;
-  constexpr int LA = BM * BK;                   // doubles per image (unpadded)
-  extern __shared__ double lds[];               // 2 * 2 * LA doubles
+  constexpr int BM = 32 * TBM, BN = 32 * TBN, TM = TBM, TN = TBN;
+  constexpr int LA = BM * BK, LB = BN * BK;     // doubles per image (unpadded)
+  extern __shared__ double lds[];               // 2 * (LA + LB) doubles
   const GemmDesc& d = p.d;
   int tm, tn, ks, bz;
   if (p.n2 >= 0) {
@@ -557,19 +559,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w & 1, wn = w >> 1;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = p.m_org + tm * BM, n0 = p.n_org + tn * BN;
   // staging geometry: instruction j of wave w covers image rows 8*(w + 4j) .. +7
   const int lrow = lane >> 3, lpair = lane & 7;
-  const double* pa[TB];
-  const double* pb[TB];
+  const double* pa[TBM];
+  const double* pb[TBN];
 #pragma unroll
-  for (int j = 0; j < TB; ++j) {
+  for (int j = 0; j < TBM; ++j) {
     int row = 8 * (w + 4 * j) + lrow;                  // tile-local row 0 .. BM-1
     int src_pair = lpair ^ ((row >> 1) & 7);           // swizzle on the source
-    int ra = m0 + row, rb = n0 + row;
+    int ra = m0 + row;
     if (ra >= d.M) ra = d.M - 1;
-    if (rb >= d.N) rb = d.N - 1;
     pa[j] = Ag + (long)ra * d.sAm + 2 * src_pair;
+  }
+#pragma unroll
+  for (int j = 0; j < TBN; ++j) {
+    int row = 8 * (w + 4 * j) + lrow;
+    int src_pair = lpair ^ ((row >> 1) & 7);
+    int rb = n0 + row;
+    if (rb >= d.N) rb = d.N - 1;
     pb[j] = Bg + (long)rb * d.sBn + 2 * src_pair;
   }
   int segc = p.kcols[ks], segcend = FLAT ? p.kcols2[ks] : p.kcols[ks + 1];
@@ -594,17 +602,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
 
   // a diagonal tile of a symmetric rank-k update (same operand, same rows): ONE panel serves as both images -- half
   // the loads of the tiles that, computing 10 of their 16 blocks, would otherwise be bound by the panel traffic
-  const bool same_panel = (Ag == Bg) && (m0 == n0) && (d.sAm == d.sBn) && (d.M == d.N);
+  const bool same_panel = (TBM == TBN) && (Ag == Bg) && (m0 == n0) && (d.sAm == d.sBn) && (d.M == d.N);
   auto issue = [&](long kb, int buf) {
-    double* sa = lds + buf * (2 * LA);
+    double* sa = lds + buf * (LA + LB);
     double* sb = sa + LA;
 #pragma unroll
-    for (int j = 0; j < TB; ++j) {
+    for (int j = 0; j < (TBM > TBN ? TBM : TBN); ++j) {
       const int r8 = 8 * (w + 4 * j);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kb),
-                                       (__attribute__((address_space(3))) void*)(sa + r8 * BK), 16, 0, 0);
-      if (!same_panel)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j] + kb),
+      if (j < TBM)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j < TBM ? j : 0] + kb),
+                                         (__attribute__((address_space(3))) void*)(sa + r8 * BK), 16, 0, 0);
+      if (j < TBN && !same_panel)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j < TBN ? j : 0] + kb),
                                          (__attribute__((address_space(3))) void*)(sb + r8 * BK), 16, 0, 0);
     }
   };
@@ -653,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
         issue(chunk_base(), cur ^ 1);
         next_chunk();
       }
-      const double* sa = lds + cur * (2 * LA);
+      const double* sa = lds + cur * (LA + LB);
       const double* sb = same_panel ? sa : sa + LA;
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
         issue(chunk_base(), cur ^ 1);
         next_chunk();
       }
-      const double* sa = lds + cur * (2 * LA);
+      const double* sa = lds + cur * (LA + LB);
       const double* sb = same_panel ? sa : sa + LA;
       if (smask != 0u) {
 #pragma unroll
@@ -824,8 +833,10 @@ static bool big_tile_attr_ok() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   if (!done[dev]) {
-    ok[dev] = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * 2 * 160 * BK * 8) == hipSuccess;
+    ok[dev] = hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 5, 5>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 160 * BK * 8) == hipSuccess &&
+              hipFuncSetAttribute((const void*)gemm_f64_kseg_lds_kernel<true, 4, 5>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 160) * BK * 8) == hipSuccess;
     done[dev] = true;
   }
   return ok[dev];
@@ -986,6 +997,7 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     p.kchunk = (int)per;
   }
   int ntile = 0;
+  if (d.tile_class >= 4 && !kflat) return gemm_fail(LRN_ERR_ARG, "gemm: tile_class 4 / 5 are for the K-contiguous rank-k update");
   if (d.tile_class != 0 && small) return gemm_fail(LRN_ERR_ARG, "gemm: tile_class needs the 128 tile");
   p.tile_list2 = nullptr;
   p.n1 = 0;
@@ -1007,11 +1019,56 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     dim3 grid1((unsigned)wgs, 1, 1);
     if (big) {
       if (!big_tile_attr_ok()) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
-      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5>), grid1, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5, 5>), grid1, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
     } else {
-      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4>), grid1, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4, 4>), grid1, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
     }
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
+  if (d.tile_class == 4 || d.tile_class == 5) {
+    // The symmetric rank-k update with a LAST TILE ROW OF HEIGHT 128 + r, r = M % 128 in (0, 32] (nvar = 4000 = 30 x 128 +
+    // 160): instead of a row of edge tiles that hold r of 128 rows -- each costs 0.7 of a full tile, bound by its panel
+    // traffic -- the last 128 + r rows are tiled on their own by 128 x 160 tiles (<true, 4, 5>), the diagonal corner
+    // included (two of those tiles, the second one with r of its 128 rows).  Orientation after the swap above: upper
+    // tiles (tn >= tm), the strip is the last tile COLUMN.  tile_class 4 launches the leading part, 5 the strip (two
+    // calls, so that the caller can time them apart).  Two launches in the caller's stream; side by side on two
+    // streams the leading part loses its lock-step (measured at C4: 502 against 488 ms as one launch with edge tiles,
+    // 486 as two launches in sequence with a corner launch of its own, which this form saves).
+    const int rem = d.M % 128;
+    if (!kflat || d.batch != 1 || big || d.M != d.N || rem == 0 || rem > 32 || d.M < 288 ||
+        (d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER)) != GEMM_TRI_UPPER || !(d.flags & GEMM_DIAG_UPPER) ||
+        (d.flags & GEMM_NO_SKIP))
+      return gemm_fail(LRN_ERR_ARG, "gemm: tile_class 4 needs the symmetric K-contiguous update with M % 128 in (0, 32]");
+    if (!big_tile_attr_ok()) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
+    const int Mm = d.M - 128 - rem, tmain = Mm / 128;
+    if (d.tile_class == 4) {   // leading part: regular tiles of every split first, its diagonal tiles last (as tile_class 3)
+      GemmParams pm = p;
+      pm.d.M = Mm; pm.d.N = Mm;
+      pm.tilesM = tmain; pm.tilesN = tmain;
+      int c1 = 0, c2 = 0;
+      pm.tile_list = get_tile_list(tmain, tmain, GEMM_TRI_UPPER, &c1, 1, false, false, true);
+      pm.tile_list2 = get_tile_list(tmain, tmain, GEMM_TRI_UPPER, &c2, 2, false, false, true);
+      if (!pm.tile_list || !pm.tile_list2) return gemm_fail(LRN_ERR_NOMEM, "gemm: tile list allocation failed");
+      pm.n1 = c1;
+      pm.n2 = c2;
+      if (c1 == 0) { pm.tile_list = pm.tile_list2; pm.n1 = c2; pm.n2 = 0; }
+      const long wgs = 8L * d.ksplit * ((pm.n1 >> 3) + (pm.n2 >> 3));
+      if (wgs > 0x7fffffffL) return gemm_fail(LRN_ERR_ARG, "gemm: grid too large");
+      if (wgs > 0)
+        hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4, 4>), dim3((unsigned)wgs, 1, 1), dim3(256),
+                           2 * 2 * 128 * BK * 8, st, pm);
+    } else {   // strip: all rows x the last 128 + r columns (entries below the diagonal of the corner are computed and never read)
+      GemmParams ps = p;
+      ps.d.flags &= ~(GEMM_TRI_LOWER | GEMM_TRI_UPPER | GEMM_DIAG_LOWER | GEMM_DIAG_UPPER);
+      ps.m_org = 0; ps.n_org = Mm;
+      ps.tilesM = tmain + 2; ps.tilesN = 1;
+      int cnt = 0;
+      ps.tile_list = get_tile_list(tmain + 2, 1, 0, &cnt);
+      if (!ps.tile_list || cnt <= 0) return gemm_fail(LRN_ERR_NOMEM, "gemm: tile list allocation failed");
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4, 5>), dim3(cnt, 1, d.ksplit), dim3(256),
+                         2 * (128 + 160) * BK * 8, st, ps);
+    }
+    return hipGetLastError() == hipSuccess ? LRN_OK : gemm_fail(LRN_ERR_HIP, "gemm: launch failed");
   }
   p.tile_list = get_tile_list(p.tilesM, p.tilesN, d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER), &ntile, d.tile_class,
                               d.tile_class != 0 && (d.M % BMv) != 0, d.tile_class != 0 && (d.N % BMv) != 0,
@@ -1028,14 +1085,14 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   if (kflat) {
     if (big) {
       if (!big_tile_attr_ok()) return gemm_fail(LRN_ERR_HIP, "gemm: 80 KB of dynamic LDS refused");
-      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5>), grid, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 5, 5>), grid, dim3(256), 2 * 2 * 160 * BK * 8, st, p);
     } else {
-      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4>), grid, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
+      hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<true, 4, 4>), grid, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
     }
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (kseg && kseg_lds_path_ok(d)) {
-    hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<false, 4>), grid, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
+    hipLaunchKernelGGL((gemm_f64_kseg_lds_kernel<false, 4, 4>), grid, dim3(256), 2 * 2 * 128 * BK * 8, st, p);
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (!small && !kseg && lds_path_ok(d)) {

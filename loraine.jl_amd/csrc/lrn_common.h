@@ -126,6 +126,8 @@ struct GemmDesc {
   int tile_class = 0;      // 0 all tiles; 1 only tiles whose blocks are all computed; 2 only the tiles with skipped blocks
                            // (edge tiles, GEMM_DIAG_* diagonal tiles) -- see get_tile_list; 3 (GEMM_KFLAT): both in one
                            // launch, class 1 of every split first, class 2 last
+  // tile_class 4 / 5 (GEMM_KFLAT, M == N, M % 128 in (0, 32]): 4 = as 3 for the leading M - 128 - M % 128 rows; 5 = the last
+  // 128 + M % 128 rows tiled by 128 x 160
   int kstagger = 0;        // GEMM_KFLAT: workgroup (tm, tn) starts its K walk ((tm + tn) & 7) * kstagger chunks into
                            // its split and wraps around (see gemm_f64_kseg_lds_kernel)
 };

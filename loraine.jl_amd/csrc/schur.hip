@@ -645,9 +645,18 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
         g3.tile_class = 2;
       } else {
         g3.tile_class = two_launches ? 3 : 0;
+        // a last tile row of height 128 + nd % 128 <= 160 instead of a row of edge tiles, as a second launch
+        // (gemm_f64.hip, tile_class 4; option "gemm3_strip")
+        if (two_launches && !t160 && c->opt.gemm3_strip && M >= 288 && M % 128 > 0 && M % 128 <= 32) g3.tile_class = 4;
       }
       LRN_TRY(gemm(c->stream, g3));
       toc(c, "gemm3");
+      if (g3.tile_class == 4) {
+        tic(c);
+        g3.tile_class = 5;
+        LRN_TRY(gemm(c->stream, g3));
+        toc(c, "gemm3s");
+      }
     }
     tic(c);
     hipLaunchKernelGGL(reduce_slabs_w_kernel, dim3(nblocks((long)M * N)), dim3(256), 0, c->stream,

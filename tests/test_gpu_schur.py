@@ -576,3 +576,31 @@ def test_gemm3_tile_and_schedule_variants_agree(dev, nvar):
     assert relerr(Hs[1], Hs[0]) < 1e-14
     A = np.stack([dev.get_constraint(0, k) for k in range(8)])
     assert relerr(Hs[0][:8, :8], np.tril(_brute_H(A, W))) < 1e-13
+
+
+@pytest.mark.parametrize("nvar", [416, 1050, 1056])
+def test_gemm3_last_tile_row_of_height_160(dev, nvar):
+    """nvar % 128 in (0, 32]: the last 128 + nvar % 128 rows of H are tiled by 128 x 160 and one 160 x 160 tile on a second
+    stream beside the 128 x 128 tiles of the leading part (gemm_f64.hip, tile_class 4; C4: 4000 = 30 x 128 + 160) instead
+    of a row of edge tiles.  Same split-K ranges, same order of the K walk: bit-identical to the edge-tile schedule."""
+    msz = 200
+    dev.synthetic_dense_model(msz, nvar, 43)
+    W, G = _spd(msz, 44)
+    dev.set_scaling(0, W, G)
+    dev.set_option("schur_chol", 1)
+    dev.set_option("gemm3_tile", 128)
+    Hs = []
+    try:
+        for strip in (1, 0, 1):
+            dev.set_option("gemm3_strip", strip)
+            Hs.append(np.tril(dev.schur_assemble(0, want_H=True)))
+    finally:
+        dev.set_option("gemm3_strip", 1)
+        dev.set_option("gemm3_tile", 0)
+        dev.set_option("schur_chol", -1)
+    assert np.array_equal(Hs[0], Hs[1]) and np.array_equal(Hs[2], Hs[1])
+    rng = np.random.default_rng(5)
+    idx = np.unique(np.r_[rng.integers(0, nvar, 6), nvar - 1, nvar - 160, nvar - 161])
+    A = np.stack([dev.get_constraint(0, int(k)) for k in idx])
+    Hfull = Hs[0] + np.tril(Hs[0], -1).T
+    assert relerr(Hfull[np.ix_(idx, idx)], _brute_H(A, W)) < 1e-13

@@ -36,12 +36,15 @@ def get(kpat, cname):
 
 with open(os.path.join(O, "l2_hit_rate.csv"), "w") as fh:
     fh.write("kernel,TCC_HIT_sum,TCC_MISS_sum,hit_rate\n")
-    for k1 in ("gemm_f64_lds_kernel<false>", "gemm_f64_lds_kernel<true>", "gemm_f64_kseg_lds_kernel<true"):
+    for k1 in ("gemm_f64_lds_kernel<false>", "gemm_f64_lds_kernel<true>", "gemm_f64_kseg_lds_kernel<true, 4, 4>",
+               "gemm_f64_kseg_lds_kernel<true, 4, 5>"):
         h, m = get(k1, "TCC_HIT_sum"), get(k1, "TCC_MISS_sum")
         if h and m:
             fh.write('"%s",%.0f,%.0f,%.4f\n' % (k1, h["total"], m["total"], h["total"] / (h["total"] + m["total"])))
 STEPS = 2        # the PMC passes of profile_r02.sh run `bench.py --steps 1 --warmup 1`: two assemblies
-for k1, label in (("gemm_f64_kseg_lds_kernel<true", "GEMM3' (1 launch per step)"), ("gemm_f64_lds_kernel<false>", "GEMM1'"),
+for k1, label in (("gemm_f64_kseg_lds_kernel<true, 4, 4>", "GEMM3' (leading rows, 128 x 128 tiles)"),
+                  ("gemm_f64_kseg_lds_kernel<true, 4, 5>", "GEMM3' strip (last 160 rows, 128 x 160 tiles)"),
+                  ("gemm_f64_lds_kernel<false>", "GEMM1'"),
                   ("gemm_f64_lds_kernel<true>", "GEMM2'")):
     mf, gui = get(k1, "SQ_VALU_MFMA_BUSY_CYCLES"), get(k1, "GRBM_GUI_ACTIVE")
     if mf and gui:
