@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -263,7 +264,8 @@ static void launch4(hipStream_t st, const GemmParams& p, bool akc, bool bkc, dim
 // registers, no ds_write pass, no per-element predicates -- rows beyond M/N and k-rows beyond K
 // are out of range of the buffer descriptor and read as zero.  Two LDS buffers, one barrier
 // per K-tile (the form the CDNA guide recommends when ~2 workgroups share a CU).
-template <bool EPI>
+// DYN: the round-2 form of the masked K-steps (a wave-uniform branch per block), kept for measurement (GEMM_DYN_MASKS).
+template <bool EPI, bool DYN>
 __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
   constexpr int LROW = BM + 16;                 // doubles per k-row of an image
@@ -382,13 +384,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     }
     __syncthreads();
   };
-  auto masked_step = [&](int kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-    const double* sa = lds + cur * (2 * LA);
-    const double* sb = sa + LA;
-    // blocks of this K-step: op(B)[k][n] = 0 for k < n (KFROM_N) means block column bn starts contributing at the
-    // K-step that reaches its first column, i.e. kt - n0/16 >= bn; KTO_N (zero for k > n): kt - n0/16 <= bn.
+  // blocks of K-step kt: op(B)[k][n] = 0 for k < n (KFROM_N) means block column bn starts contributing at the K-step
+  // that reaches its first column, i.e. kt - n0/16 >= bn; KTO_N (zero for k > n): kt - n0/16 <= bn.
+  auto step_mask = [&](int kt) __attribute__((always_inline)) -> unsigned {
     unsigned mask = smask;
     const int sn = kt - n0 / BK, sm = kt - m0 / BK;
 #pragma unroll
@@ -401,6 +399,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
       const int bm = 2 * i + wm;
       if ((from_m && sm < bm) || (to_m && sm > bm)) mask &= ~(0xfu << (4 * i));
     }
+    return mask;
+  };
+  auto masked_step = [&](int kt, unsigned mask) __attribute__((always_inline)) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+    const double* sa = lds + cur * (2 * LA);
+    const double* sb = sa + LA;
     if (mask != 0u) {
       // all fragments of the K-step first (one exposed LDS latency instead of four: nothing is scheduled across the
       // branches below), then the needed blocks
@@ -422,23 +427,108 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     }
     __syncthreads();
   };
-  int head_end = kt0, tail_begin = nk;          // K-steps [kt0, head_end) and [tail_begin, nk) run masked
-  if (smask != 0xffffu) {
-    head_end = nk;
-  } else {
-    if (from_n | from_m) head_end = kt0 + 8 < nk ? kt0 + 8 : nk;
-    if (to_n) tail_begin = n0 / BK;
-    if (to_m && m0 / BK < tail_begin) tail_begin = m0 / BK;
-    if (d.flags & GEMM_NO_SKIP) { head_end = kt0; tail_begin = nk; }
-    if (tail_begin < head_end) tail_begin = head_end;
-    if (tail_begin > nk) tail_begin = nk;
-  }
+  // A K-step whose set of blocks is one of the common patterns, as straight-line code (round 3): the compiler's own
+  // schedule of fragment reads and builtin MFMAs, only the fragments the pattern needs.  The patterns: a prefix of the
+  // wave's block rows or columns (the triangular head of a K range, step by step; the edge tiles of msz % 128 != 0),
+  // and the blocks on and above the diagonal of a packed diagonal tile.  Any other set of blocks runs the smallest
+  // pattern that contains it: a block outside the set multiplies explicit zeros (the other triangle of a triangular
+  // operand is stored as zeros, rows beyond M / N read as zeros) or is never stored (packed diagonal tiles) -- what
+  // GEMM_NO_SKIP does for every block.  The branch-per-block body above (round 2; with it next to these bodies the
+  // register allocator spills the accumulators) ran the blocks it executed at 0.76 of the unmasked loop's rate.
+  auto static_step = [&](auto mc, int kt) __attribute__((always_inline)) {
+    constexpr unsigned MK = decltype(mc)::value;
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+    const double* sa = lds + cur * (2 * LA);
+    const double* sb = sa + LA;
+    // (a distinct marker per pattern: identical fragment reads at the head of the branches below must not be merged
+    // above them -- see the note on the two loop bodies)
+    asm volatile("; static K-step, block pattern %0" ::"n"(MK) : "memory");
+    if (MK != 0u) {
+      // in-place MFMAs (with builtin MFMAs the accumulators of the many bodies meet in PHI copies and spill); the
+      // statements keep their order, so the fragments of quarter kk + 1 are requested before the MFMAs of quarter kk
+      double fa[2][TM], fb[2][TN];
+      auto frags = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          if (MK & (0xfu << (4 * i))) fa[kk & 1][i] = sa[(kk * 4 + fk) * LROW + (2 * i + wm) * 16 + fr];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (MK & (0x1111u << j)) fb[kk & 1][j] = sb[(kk * 4 + fk) * LROW + (2 * j + wn) * 16 + fr];
+      };
+      frags(0);
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        if (kk + 1 < BK / 4) frags(kk + 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (MK & (1u << (i * 4 + j))) LRN_MFMA_INPLACE(acc[i][j], fa[kk & 1][i], fb[kk & 1][j]);
+      }
+    }
+    __syncthreads();
+  };
   issue(kt0, kt0 & 1);
   __syncthreads();
   int kt = kt0;
-  for (; kt < head_end; ++kt) masked_step(kt);
-  for (; kt < tail_begin; ++kt) fast_step(kt);
-  for (; kt < nk; ++kt) masked_step(kt);
+  if constexpr (DYN) {
+    int head_end = kt0, tail_begin = nk;          // K-steps [kt0, head_end) and [tail_begin, nk) run block by block
+    if (smask != 0xffffu) {
+      head_end = nk;
+    } else {
+      if (from_n | from_m) head_end = kt0 + 8 < nk ? kt0 + 8 : nk;
+      if (to_n) tail_begin = n0 / BK;
+      if (to_m && m0 / BK < tail_begin) tail_begin = m0 / BK;
+      if (d.flags & GEMM_NO_SKIP) { head_end = kt0; tail_begin = nk; }
+      if (tail_begin < head_end) tail_begin = head_end;
+      if (tail_begin > nk) tail_begin = nk;
+    }
+    for (; kt < head_end; ++kt) masked_step(kt, step_mask(kt));
+    for (; kt < tail_begin; ++kt) fast_step(kt);
+    for (; kt < nk; ++kt) masked_step(kt, step_mask(kt));
+  } else {
+    // A SEQUENCE of simple loops, one per pattern, each over its range of K-steps (empty for most tiles): as branches of
+    // one loop body the accumulators of the bodies meet in copies and spill.
+    //  * a tile whose 16 blocks are all needed, triangular operand (KFROM): wave column wn meets block column bn = 2 j + wn
+    //    at K-step kt0 + bn -- no block during the first wn steps, then j < 1, 2, 3 for two steps each, then the
+    //    unmasked loop; KFROM_M the same with block rows;
+    //  * a tile with skipped blocks (edge, packed diagonal tile): the smallest pattern that contains its blocks, for all
+    //    its K-steps (a block of the head computed too early multiplies stored zeros);
+    //  * the K-steps of a KTO tail run unmasked (stored zeros again).
+    int e[10];                                    // end of the K-steps of pattern q (see the loops below)
+#pragma unroll
+    for (int q = 0; q < 10; ++q) e[q] = kt0;
+    if (smask == 0xffffu) {
+      if ((from_n | from_m) && !(d.flags & GEMM_NO_SKIP)) {
+        const int w0 = kt0 + (from_n ? wn : wm);
+        e[0] = w0;
+        if (from_n) { e[1] = w0 + 2; e[2] = w0 + 4; e[3] = w0 + 6; }
+        else { e[4] = w0 + 2; e[5] = w0 + 4; e[6] = w0 + 6; }
+      }
+    } else if (!(d.flags & GEMM_NO_SKIP)) {
+      // (smallest first)
+      if ((smask & ~0x1111u) == 0u) e[1] = nk;
+      else if ((smask & ~0x000fu) == 0u) e[4] = nk;
+      else if ((smask & ~0x08ceu) == 0u) e[7] = nk;
+      else if ((smask & ~0x3333u) == 0u) e[2] = nk;
+      else if ((smask & ~0x00ffu) == 0u) e[5] = nk;
+      else if ((smask & ~0x8cefu) == 0u) e[8] = nk;
+      else if ((smask & ~0x7777u) == 0u) e[3] = nk;
+      else if ((smask & ~0x0fffu) == 0u) e[6] = nk;
+    }
+#define LRN_PATTERN_LOOP(q, m)                                                             \
+    {                                                                                      \
+      const int end = e[q] < nk ? e[q] : nk;                                               \
+      for (; kt < end; ++kt) static_step(std::integral_constant<unsigned, m>{}, kt);       \
+    }
+    LRN_PATTERN_LOOP(0, 0x0000u)
+    LRN_PATTERN_LOOP(1, 0x1111u) LRN_PATTERN_LOOP(2, 0x3333u) LRN_PATTERN_LOOP(3, 0x7777u)     // block columns 0 .. NJ-1 of the wave
+    LRN_PATTERN_LOOP(4, 0x000fu) LRN_PATTERN_LOOP(5, 0x00ffu) LRN_PATTERN_LOOP(6, 0x0fffu)     // block rows 0 .. NI-1
+    LRN_PATTERN_LOOP(7, 0x08ceu) LRN_PATTERN_LOOP(8, 0x8cefu)                                   // packed diagonal tile: bn > bm, bn >= bm
+#undef LRN_PATTERN_LOOP
+    for (; kt < nk; ++kt) fast_step(kt);
+  }
   LRN_MFMA_DRAIN();
 
   const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
@@ -1096,8 +1186,13 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (!small && !kseg && lds_path_ok(d)) {
-    if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_f64_lds_kernel<false>), grid, dim3(256), 0, st, p);
+    if (d.flags & GEMM_DYN_MASKS) {
+      if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true, true>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_f64_lds_kernel<false, true>), grid, dim3(256), 0, st, p);
+    } else {
+      if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true, false>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_f64_lds_kernel<false, false>), grid, dim3(256), 0, st, p);
+    }
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (small) {

@@ -61,6 +61,8 @@ enum : int {
                            // the diagonal (m >= n) are computed and stored (the caller never reads the others)
   GEMM_DIAG_UPPER = 16384, // same for n >= m (what GEMM_DIAG_LOWER becomes when gemm() transposes the problem)
   GEMM_TILE160 = 65536,    // GEMM_KFLAT only: 160 x 160 workgroup tile (gemm_f64_kseg_lds_kernel<true, 5>)
+  GEMM_DYN_MASKS = 131072, // measurement only (option "gemm_dyn_masks"): no straight-line K-steps for the common block
+                           // patterns, every masked K-step branches per block (the round-2 kernel)
   GEMM_NO_SKIP = 32768,    // measurement only (option "gemm_no_skip"): compute every block of every tile
   GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower layout;
                            // the first kflat_nsd splits cover the diagonal blocks [0, kflat_diag), the

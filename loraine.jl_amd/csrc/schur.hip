@@ -510,7 +510,8 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g1.B = Ut + off; g1.sBk = m; g1.sBn = 1; g1.bB = 0;     // op(B)[k][j] = L[k,j] = Ut[j + k*m]
       g1.C = P; g1.sCm = ldp; g1.sCn = 1; g1.bC = p_elems;
       g1.M = g1.K = m - c0; g1.N = c1 - c0; g1.batch = nb;
-      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
+      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
+                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0);
       LRN_TRY(gemm(c->stream, g1));
       toc(c, "gemm1");
       tic(c);
@@ -520,7 +521,8 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g2.C = T + (long)a * 16; g2.sCm = 1; g2.sCn = m; g2.bC = 16;
       g2.pk_cstride = cstride;
       g2.M = g2.K = m - c0; g2.N = c1 - c0; g2.batch = nb;
-      g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
+      g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
+                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0);
       g2.pk_m = m;
       g2.pk_off = c0;
       LRN_TRY(gemm(c->stream, g2));
@@ -754,7 +756,8 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
       g1.B = Ut; g1.sBk = m; g1.sBn = 1; g1.bB = 0;
       g1.C = P; g1.sCm = m; g1.sCn = 1; g1.bC = mm;
       g1.M = g1.N = g1.K = m; g1.batch = nb;
-      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0);
+      g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
+                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0);
       LRN_TRY(gemm(c->stream, g1));
       GemmDesc g2;   // At = L' P, tiles i >= j (K from the tile's row origin), mirrored: full symmetric, col-major
       g2.A = Ut; g2.sAm = 1; g2.sAk = m; g2.bA = 0;
