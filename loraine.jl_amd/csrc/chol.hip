@@ -98,6 +98,119 @@ __global__ __launch_bounds__(64) void potrf_diag_wave_kernel(double* __restrict_
     if (i < nb && j < nb && i >= j) A[(long)i + (long)j * ld] = a[j];
 }
 
+// The diagonal block by FOUR wavefronts in eight panels of 8 columns (round 3).  The one-wave kernel above spends 28 of
+// its 37.5 us in the per-column chain -- pivot broadcast, sqrt, divide, an LDS round trip -- in front of 63 - j FMAs that
+// the in-order wave cannot overlap with it.  Here the block lives in LDS; wave 0 factors a 64 x 8 panel with the rows in
+// 8 registers per lane (the chain: v_readlane of the pivot, v_rsq_f64 + one Goldschmidt and one Newton step -- 8 dependent
+// operations instead of the ~45 of sqrt and divide -- and at most 7 lagging FMAs per column, their multipliers by
+// v_readlane), then all four waves apply the rank-8 update to the 16 x 16 blocks of the trailing part on the MFMA
+// (two v_mfma_f64_16x16x4 per block; block columns that the panel itself crosses are masked in the B operand).
+// Entries above the diagonal are scratch.  Same pivot rules as above (boosting, first failing column in info[0]).
+__device__ __forceinline__ void rsqrt_pair(double p, double& sq, double& rinv) {
+  if (p > 1e-280 && p < 1e280) {
+    const double y = __builtin_amdgcn_rsq(p);
+    double g = p * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double dd = fma(-g, g, p);
+    g = fma(dd, h, g);                    // sqrt(p), one Newton correction
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);                     // 1 / (2 sqrt(p))
+    sq = g;
+    rinv = 2.0 * h;
+  } else {
+    sq = sqrt(p);
+    rinv = 1.0 / sq;
+  }
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_blk_kernel(double* __restrict__ A, int ld, int nb, int col0,
+                                                             int* __restrict__ info, const double* __restrict__ diag0,
+                                                             double boost, int max_boost) {
+  __shared__ double M[NB][NB + 1];
+  __shared__ int bad_s;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (*info != 0) return;
+  for (int e = t; e < NB * NB; e += 256) {
+    const int i = e % NB, j = e / NB;
+    M[i][j] = (i < nb && j < nb && i >= j) ? A[(long)i + (long)j * ld] : (i == j ? 1.0 : 0.0);
+  }
+  if (t == 0) bad_s = 0;
+  double d0v = 1.0;                              // wave 0, lane j: original diagonal entry of column col0 + j
+  if (w == 0 && diag0 && lane < nb) d0v = diag0[col0 + lane];
+  __syncthreads();
+  for (int p8 = 0; p8 < NB / 8; ++p8) {
+    const int c0 = 8 * p8;
+    if (w == 0) {
+      double pr[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pr[q] = M[lane][c0 + q];
+      int bad = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = c0 + q;
+        if (bad == 0) {
+          double piv = readlane_f64(pr[q], j);
+          if (diag0 && j < nb) {
+            const double d0 = readlane_f64(d0v, j);
+            if (d0 > 0.0 && piv <= boost * d0 && piv == piv) {
+              piv = 1e40 * fmax(fabs(d0), 1.0);
+              int cnt = 0;
+              if (lane == 0) cnt = atomicAdd(info + 1, 1) + 1;
+              cnt = __builtin_amdgcn_readfirstlane(cnt);
+              if (cnt > max_boost) bad = col0 + j + 1;
+            }
+          }
+          if (!(piv > 0.0)) bad = col0 + j + 1;        // also catches NaN; wave-uniform
+          if (bad == 0) {
+            double sq, rinv;
+            rsqrt_pair(piv, sq, rinv);
+            const double lij = pr[q] * rinv;
+            pr[q] = (lane == j) ? sq : lij;
+#pragma unroll
+            for (int k = q + 1; k < 8; ++k) pr[k] -= lij * readlane_f64(lij, c0 + k);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) M[lane][c0 + q] = pr[q];
+      if (bad && lane == 0) bad_s = bad;
+    }
+    __syncthreads();
+    if (bad_s) break;
+    // rank-8 update of the blocks (I, J), I >= J, that hold columns >= c0 + 8
+    const int c1 = c0 + 8, Jmin = c1 >> 4;
+    int cnt = 0;
+    for (int J = Jmin; J < NB / 16; ++J)
+      for (int I = J; I < NB / 16; ++I, ++cnt) {
+        if ((cnt & 3) != w) continue;
+        const int cr = lane >> 4, cc = lane & 15;
+        v4f64 c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = M[16 * I + cr + 4 * r][16 * J + cc];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const double a = -M[16 * I + cc][c0 + 4 * kk + cr];
+          const double b = (16 * J + cc >= c1) ? M[16 * J + cc][c0 + 4 * kk + cr] : 0.0;
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[16 * I + cr + 4 * r][16 * J + cc] = c[r];
+      }
+    __syncthreads();
+  }
+  if (bad_s) {
+    if (t == 0) atomicCAS(info, 0, bad_s);
+    return;
+  }
+  for (int e = t; e < NB * NB; e += 256) {
+    const int i = e % NB, j = e / NB;
+    if (i < nb && j < nb && i >= j) A[(long)i + (long)j * ld] = M[i][j];
+  }
+}
+
 // Panel of the factorisation: rows of A21 (rem x NB, ld) solve  x L_kk' = a  by forward substitution,
 // one thread per row with the row in registers and L_kk (NB x NB, lower, full block) in LDS.
 // Writes the result back in place and into the contiguous work panel W (rem x NB, ld rem).
@@ -284,8 +397,13 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
     int k0 = b * NB;
     int nb = n - k0 < NB ? n - k0 : NB;
     double* Akk = A + (long)k0 + (long)k0 * ld;
-    hipLaunchKernelGGL(potrf_diag_wave_kernel, dim3(1), dim3(64), 0, st, Akk, ld, nb, k0, info_dev, diag0, boost,
-                       max_boost);
+    static const bool diag_wave = getenv("LRN_POTRF_DIAG1") != nullptr;       // (measurement: the one-wave kernel)
+    if (diag_wave)
+      hipLaunchKernelGGL(potrf_diag_wave_kernel, dim3(1), dim3(64), 0, st, Akk, ld, nb, k0, info_dev, diag0, boost,
+                         max_boost);
+    else
+      hipLaunchKernelGGL(potrf_diag_blk_kernel, dim3(1), dim3(256), 0, st, Akk, ld, nb, k0, info_dev, diag0, boost,
+                         max_boost);
     int rem = n - k0 - nb;
     if (rem <= 0) break;
     // panel: Wk = A21 * Lkk^-T      (rem x nb), by substitution

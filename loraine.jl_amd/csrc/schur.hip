@@ -382,9 +382,12 @@ static std::vector<std::pair<int, int>> col_runs(int m, int nd, int rank, int wo
 // Matrices per launch of the triangular-K products: their workgroups differ in length, so every launch ends with a
 // drain of about half the longest workgroup -- fewer, larger launches (measured at C4: GEMM1'+GEMM2' 569 / 555 /
 // 547 / 545 ms per step with 64 / 128 / 256 / 500 matrices per launch); up to 8.6 GB of P workspace.
-static long tri_p_batch(int m) {
-  long p = (long)(8.6e9 / ((double)m * m * 8.0));
-  return std::max<long>(16, std::min<long>(256, p));
+// Round 3: with the masked K-steps cheaper the drains show again -- 16 / 8 / 4 / 2 launches per step: GEMM1' 335.8 / 335.3 /
+// 333.6 / 334.3, GEMM2' 177.1 / 176.4 / 175.3 / 175.2 ms; `large` = up to 34 GB (1000 matrices at C4) where the memory
+// is there (chol_path_applicable).
+static long tri_p_batch(int m, bool large = false) {
+  long p = (long)((large ? 34.4e9 : 8.6e9) / ((double)m * m * 8.0));
+  return std::max<long>(16, std::min<long>(large ? 1024 : 256, p));
 }
 
 static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
@@ -409,6 +412,11 @@ static bool chol_path_applicable(lrn_ctx* c, LmiBlock& b, long* pcap_out) {
   double avail = ((double)free_b + (double)c->T.bytes + (double)c->P.bytes) * 0.92;
   double need = (double)b.nd * packed_total_elems(b.msz) * 8.0 + (double)pcap * mm * 8.0 + 10.0e9;   // + split-K slabs
   if (need > avail) return false;
+  if (c->opt.p_batch <= 0 && c->world == 1) {
+    // fewer, larger launches of GEMM1'/2' where a tenth of the memory stays free after them
+    const long big = std::min<long>(tri_p_batch(b.msz, true), b.nd);
+    if (big > pcap && need + (double)(big - pcap) * mm * 8.0 + 0.10 * (double)total_b <= avail / 0.92) *pcap_out = big;
+  }
   return true;
 }
 
