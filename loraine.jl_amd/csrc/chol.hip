@@ -144,33 +144,65 @@ __global__ __launch_bounds__(256) void potrf_diag_blk_kernel(double* __restrict_
   for (int p8 = 0; p8 < NB / 8; ++p8) {
     const int c0 = 8 * p8;
     if (w == 0) {
-      double pr[8];
+      double pr[8], pr0[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) pr[q] = M[lane][c0 + q];
+      for (int q = 0; q < 8; ++q) pr0[q] = pr[q] = M[lane][c0 + q];
       int bad = 0;
+      // the eight columns as straight-line code (the lagging FMAs of a column fill the latency of the next column's
+      // chain): valid if every pivot is an ordinary positive number above the boosting threshold; otherwise the panel
+      // is redone from its saved registers by the careful loop below (rare: a numerically singular Schur matrix)
+      bool ok = true;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int j = c0 + q;
-        if (bad == 0) {
-          double piv = readlane_f64(pr[q], j);
-          if (diag0 && j < nb) {
-            const double d0 = readlane_f64(d0v, j);
-            if (d0 > 0.0 && piv <= boost * d0 && piv == piv) {
-              piv = 1e40 * fmax(fabs(d0), 1.0);
-              int cnt = 0;
-              if (lane == 0) cnt = atomicAdd(info + 1, 1) + 1;
-              cnt = __builtin_amdgcn_readfirstlane(cnt);
-              if (cnt > max_boost) bad = col0 + j + 1;
-            }
-          }
-          if (!(piv > 0.0)) bad = col0 + j + 1;        // also catches NaN; wave-uniform
-          if (bad == 0) {
-            double sq, rinv;
-            rsqrt_pair(piv, sq, rinv);
-            const double lij = pr[q] * rinv;
-            pr[q] = (lane == j) ? sq : lij;
+        const double piv = readlane_f64(pr[q], j);
+        double lo = 1e-280;
+        if (diag0 && j < nb) {
+          const double d0 = readlane_f64(d0v, j);
+          if (d0 > 0.0) lo = fmax(lo, boost * d0);
+        }
+        ok = ok && (piv > lo) && (piv < 1e280);
+        const double y = __builtin_amdgcn_rsq(piv);
+        double g = piv * y, h = 0.5 * y;
+        double r = fma(-h, g, 0.5);
+        g = fma(g, r, g);
+        h = fma(h, r, h);
+        const double dd = fma(-g, g, piv);
+        g = fma(dd, h, g);
+        r = fma(-h, g, 0.5);
+        h = fma(h, r, h);
+        const double lij = pr[q] * (2.0 * h);
+        pr[q] = (lane == j) ? g : lij;
 #pragma unroll
-            for (int k = q + 1; k < 8; ++k) pr[k] -= lij * readlane_f64(lij, c0 + k);
+        for (int k = q + 1; k < 8; ++k) pr[k] -= lij * readlane_f64(lij, c0 + k);
+      }
+      if (!ok) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pr[q] = pr0[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int j = c0 + q;
+          if (bad == 0) {
+            double piv = readlane_f64(pr[q], j);
+            if (diag0 && j < nb) {
+              const double d0 = readlane_f64(d0v, j);
+              if (d0 > 0.0 && piv <= boost * d0 && piv == piv) {
+                piv = 1e40 * fmax(fabs(d0), 1.0);
+                int cnt = 0;
+                if (lane == 0) cnt = atomicAdd(info + 1, 1) + 1;
+                cnt = __builtin_amdgcn_readfirstlane(cnt);
+                if (cnt > max_boost) bad = col0 + j + 1;
+              }
+            }
+            if (!(piv > 0.0)) bad = col0 + j + 1;        // also catches NaN; wave-uniform
+            if (bad == 0) {
+              double sq, rinv;
+              rsqrt_pair(piv, sq, rinv);
+              const double lij = pr[q] * rinv;
+              pr[q] = (lane == j) ? sq : lij;
+#pragma unroll
+              for (int k = q + 1; k < 8; ++k) pr[k] -= lij * readlane_f64(lij, c0 + k);
+            }
           }
         }
       }
@@ -310,6 +342,78 @@ __global__ __launch_bounds__(256) void potrf_panel8_kernel(double* __restrict__ 
   }
 }
 
+// The panel solve by strips of 16 rows, one wavefront per strip, no barrier after the prologue (round 3).  The strip
+// X (16 x 64) stays in registers as four 16 x 16 blocks in the MFMA result layout.  For each block column c: the block
+// goes to LDS, lanes 0..15 (one row each) solve it against the 16 x 16 diagonal sub-block of L_kk right-looking -- a
+// dependent chain of 16 multiply / FMA pairs, the multipliers l_kj as LDS broadcasts -- and the blocks c' > c take
+// X_c L[c', c]' off on the MFMA (4 x v_mfma_f64_16x16x4 each).  Critical path per strip: 4 x (16-step chain + 4 MFMAs)
+// instead of the 8 x (36 + 64) dependent FMA / LDS pairs and 8 barriers of the eight-lane kernel above
+// (19 us at n = 800, 32 us at n = 4000).  No inverse of the diagonal sub-blocks: substitution, as everywhere in this file.
+__global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restrict__ A21, int ld, int rem,
+                                                               const double* __restrict__ Lkk, double* __restrict__ W,
+                                                               const int* __restrict__ info) {
+  __shared__ double Ls[NB][NB + 1];
+  __shared__ double rinv[NB];
+  __shared__ double Xs[4][16][NB + 1];
+  if (*info != 0) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  for (int e = t; e < NB * NB; e += 256) {
+    const int i = e % NB, j = e / NB;
+    Ls[i][j] = i >= j ? Lkk[(long)i + (long)j * ld] : 0.0;
+  }
+  if (t < NB) rinv[t] = 1.0 / Lkk[(long)t + (long)t * ld];
+  const int row0 = blockIdx.x * 64 + 16 * w;
+  const int cr = lane >> 4, cc = lane & 15;
+  v4f64 C[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + cr + 4 * r;
+      C[cb][r] = row < rem ? A21[(long)row + (long)(16 * cb + cc) * ld] : 0.0;
+    }
+  __syncthreads();
+  if (row0 >= rem) return;
+  double (*X)[NB + 1] = Xs[w];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[cr + 4 * r][16 * c + cc] = C[c][r];
+    if (lane < 16) {
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = X[lane][16 * c + k];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        x[j] *= rinv[16 * c + j];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) x[k] -= x[j] * Ls[16 * c + k][16 * c + j];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) X[lane][16 * c + k] = x[k];
+    }
+#pragma unroll
+    for (int c2 = c + 1; c2 < 4; ++c2)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double a = -X[cc][16 * c + 4 * kk + cr];
+        const double b = Ls[16 * c2 + cc][16 * c + 4 * kk + cr];
+        C[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[c2], 0, 0, 0);
+      }
+  }
+  // the strip, rows fastest
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = row0 + cc, col = cr + 4 * i;
+    if (row < rem) {
+      const double v = X[cc][col];
+      A21[(long)row + (long)col * ld] = v;
+      W[(long)row + (long)col * rem] = v;
+    }
+  }
+}
+
 // Diagonal step of the matrix solves: X_b = L_kk^-1 B_b (trans = 0) or L_kk^-T B_b (trans = 1) for the
 // block rows [k0, k0 + nb) of B (ldb), one thread per right-hand side; result in place and in
 // tmp (NB x nrhs, ld NB).
@@ -408,8 +512,12 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
     if (rem <= 0) break;
     // panel: Wk = A21 * Lkk^-T      (rem x nb), by substitution
     static const bool one_lane = getenv("LRN_POTRF_PANEL1") != nullptr;
+    static const bool eight_lanes = getenv("LRN_POTRF_PANEL8") != nullptr;   // (measurement: the round-3a kernel)
     if (one_lane || nb < NB)
       hipLaunchKernelGGL(potrf_panel_kernel, dim3((rem + 255) / 256), dim3(256), 0, st,
+                         A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
+    else if (!eight_lanes)
+      hipLaunchKernelGGL(potrf_panel_mfma_kernel, dim3((rem + 63) / 64), dim3(256), 0, st,
                          A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
     else
       hipLaunchKernelGGL(potrf_panel8_kernel, dim3((rem + 31) / 32), dim3(256), 0, st,
