@@ -125,22 +125,14 @@ __device__ __forceinline__ void rsqrt_pair(double p, double& sq, double& rinv) {
   }
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_blk_kernel(double* __restrict__ A, int ld, int nb, int col0,
-                                                             int* __restrict__ info, const double* __restrict__ diag0,
-                                                             double boost, int max_boost) {
-  __shared__ double M[NB][NB + 1];
-  __shared__ int bad_s;
+// (M holds the block -- lower part, identity-padded beyond nb -- and bad_s = 0, visible to the whole workgroup on entry;
+// on return M holds the factor, or bad_s the failing column; ends with a barrier)
+__device__ __forceinline__ void diag_block_factor(double (*M)[NB + 1], int& bad_s, int nb, int col0, int* __restrict__ info,
+                                                  const double* __restrict__ diag0, double boost, int max_boost) {
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  if (*info != 0) return;
-  for (int e = t; e < NB * NB; e += 256) {
-    const int i = e % NB, j = e / NB;
-    M[i][j] = (i < nb && j < nb && i >= j) ? A[(long)i + (long)j * ld] : (i == j ? 1.0 : 0.0);
-  }
-  if (t == 0) bad_s = 0;
   double d0v = 1.0;                              // wave 0, lane j: original diagonal entry of column col0 + j
   if (w == 0 && diag0 && lane < nb) d0v = diag0[col0 + lane];
-  __syncthreads();
   for (int p8 = 0; p8 < NB / 8; ++p8) {
     const int c0 = 8 * p8;
     if (w == 0) {
@@ -233,6 +225,22 @@ __global__ __launch_bounds__(256) void potrf_diag_blk_kernel(double* __restrict_
       }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_blk_kernel(double* __restrict__ A, int ld, int nb, int col0,
+                                                             int* __restrict__ info, const double* __restrict__ diag0,
+                                                             double boost, int max_boost) {
+  __shared__ double M[NB][NB + 1];
+  __shared__ int bad_s;
+  const int t = threadIdx.x;
+  if (*info != 0) return;
+  for (int e = t; e < NB * NB; e += 256) {
+    const int i = e % NB, j = e / NB;
+    M[i][j] = (i < nb && j < nb && i >= j) ? A[(long)i + (long)j * ld] : (i == j ? 1.0 : 0.0);
+  }
+  if (t == 0) bad_s = 0;
+  __syncthreads();
+  diag_block_factor(M, bad_s, nb, col0, info, diag0, boost, max_boost);
   if (bad_s) {
     if (t == 0) atomicCAS(info, 0, bad_s);
     return;
@@ -414,6 +422,100 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
   }
 }
 
+// Trailing update of the factorisation, A22 -= Wk Wk' on the lower 64 x 64 tiles (Wk: rem x 64, contiguous), as a
+// kernel of its own (round 3).  The general GEMM walks K = 64 in four 16-steps with a barrier each and reads C in its
+// epilogue: five dependent global round trips for 2 MFLOP per tile -- 42 us per update at n = 4000 (two thirds of the
+// factorisation), 12 us at n = 800.  Here a workgroup requests its C tile (into the accumulators, MFMA result layout, the
+// lane-contiguous dimension along the columns of A22 in memory) and its two 64 x 64 panels at once -- ONE round trip --
+// then runs 64 MFMAs per wave from LDS and stores the tile.
+// The workgroup of tile (0, 0) -- the next diagonal block -- goes on to factor it (diag_block_factor) from LDS instead
+// of storing it for a kernel of its own: one launch and one global round trip less per block column, and the pivot
+// chain of block k + 1 runs beside the other tiles of update k.  (The sums start from zero and meet C once at the
+// end, like in the general GEMM: starting from C costs a factor 5 in the backward error.)
+__global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ C, int ld, int rem,
+                                                         const double* __restrict__ Wp, int* __restrict__ info,
+                                                         int fuse_diag, int col0, const double* __restrict__ diag0,
+                                                         double boost, int max_boost) {
+  constexpr int LS = NB + 8;     // k-rows 16 banks apart: every bank is hit by two of the 64 lanes of a fragment read -- the two
+                                 // passes 512 bytes take anyway; with NB + 16 the two panels fill 80 KB and one workgroup a CU
+  __shared__ double PA[NB][LS];
+  __shared__ double PB[NB][LS];
+  __shared__ int bad_s;
+  const int I = blockIdx.x, J = blockIdx.y;        // tile row / column of A22
+  if (J > I) return;
+  if (*info != 0) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i0 = NB * I, j0 = NB * J;
+  const int cr = lane >> 4, cc = lane & 15;
+  // the C tile: wave w owns columns j0 + 16 w .. + 15 of the tile, all 64 rows (four 16 x 16 blocks)
+  v4f64 cv[4], acc[4];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 16 * bb + cc, j = j0 + 16 * w + cr + 4 * r;
+      cv[bb][r] = (i < rem && j < rem) ? C[(long)i + (long)j * ld] : 0.0;
+      acc[bb][r] = 0.0;
+    }
+  {
+    const int row = t & 63, kq = t >> 6;
+    double va[16], vb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = kq + 4 * q;
+      va[q] = (j0 + row < rem) ? Wp[(long)(j0 + row) + (long)k * rem] : 0.0;
+      vb[q] = (I != J && i0 + row < rem) ? Wp[(long)(i0 + row) + (long)k * rem] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      PA[kq + 4 * q][row] = va[q];
+      if (I != J) PB[kq + 4 * q][row] = vb[q];
+    }
+  }
+  if (t == 0) bad_s = 0;
+  __syncthreads();
+  const double (*Pb)[LS] = (I != J) ? PB : PA;
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    const double a = PA[4 * kk + cr][16 * w + cc];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+      acc[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Pb[4 * kk + cr][16 * bb + cc], acc[bb], 0, 0, 0);
+  }
+  if (fuse_diag && I == 0 && J == 0) {
+    // this tile is the next diagonal block: factor it here
+    const int nb = rem < NB ? rem : NB;
+    __syncthreads();                               // (every wave is done with the panels)
+    double (*M)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(&PA[0][0]);
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * bb + cc, j = 16 * w + cr + 4 * r;
+        M[i][j] = (i < nb && j < nb && i >= j) ? cv[bb][r] - acc[bb][r] : (i == j ? 1.0 : 0.0);
+      }
+    __syncthreads();
+    diag_block_factor(M, bad_s, nb, col0, info, diag0, boost, max_boost);
+    if (bad_s) {
+      if (t == 0) atomicCAS(info, 0, bad_s);
+      return;
+    }
+    for (int e = t; e < NB * NB; e += 256) {
+      const int i = e % NB, j = e / NB;
+      if (i < nb && j < nb && i >= j) C[(long)i + (long)j * ld] = M[i][j];
+    }
+    return;
+  }
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 16 * bb + cc, j = j0 + 16 * w + cr + 4 * r;
+      if (i < rem && j < rem) C[(long)i + (long)j * ld] = cv[bb][r] - acc[bb][r];
+    }
+}
+
 // Diagonal step of the matrix solves: X_b = L_kk^-1 B_b (trans = 0) or L_kk^-T B_b (trans = 1) for the
 // block rows [k0, k0 + nb) of B (ldb), one thread per right-hand side; result in place and in
 // tmp (NB x nrhs, ld NB).
@@ -497,22 +599,28 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
                       const double* diag0, double boost, int max_boost) {
   // work: n x NB doubles
   int nblk = (n + NB - 1) / NB;
+  static const bool diag_wave = getenv("LRN_POTRF_DIAG1") != nullptr;       // (measurement: the one-wave kernel)
+  static const bool one_lane = getenv("LRN_POTRF_PANEL1") != nullptr;
+  static const bool eight_lanes = getenv("LRN_POTRF_PANEL8") != nullptr;    // (measurement: the round-3a kernel)
+  static const bool use_gemm = getenv("LRN_POTRF_GEMM") != nullptr;         // (measurement: the general GEMM, as in round 2)
+  static const bool no_fuse = getenv("LRN_POTRF_NOFUSE") != nullptr;        // (measurement: diagonal blocks as launches of their own)
+  bool diag_done = false;                 // the diagonal block of this step was factored by the previous update kernel
   for (int b = 0; b < nblk; ++b) {
     int k0 = b * NB;
     int nb = n - k0 < NB ? n - k0 : NB;
     double* Akk = A + (long)k0 + (long)k0 * ld;
-    static const bool diag_wave = getenv("LRN_POTRF_DIAG1") != nullptr;       // (measurement: the one-wave kernel)
-    if (diag_wave)
-      hipLaunchKernelGGL(potrf_diag_wave_kernel, dim3(1), dim3(64), 0, st, Akk, ld, nb, k0, info_dev, diag0, boost,
-                         max_boost);
-    else
-      hipLaunchKernelGGL(potrf_diag_blk_kernel, dim3(1), dim3(256), 0, st, Akk, ld, nb, k0, info_dev, diag0, boost,
-                         max_boost);
+    if (!diag_done) {
+      if (diag_wave)
+        hipLaunchKernelGGL(potrf_diag_wave_kernel, dim3(1), dim3(64), 0, st, Akk, ld, nb, k0, info_dev, diag0, boost,
+                           max_boost);
+      else
+        hipLaunchKernelGGL(potrf_diag_blk_kernel, dim3(1), dim3(256), 0, st, Akk, ld, nb, k0, info_dev, diag0, boost,
+                           max_boost);
+    }
+    diag_done = false;
     int rem = n - k0 - nb;
     if (rem <= 0) break;
     // panel: Wk = A21 * Lkk^-T      (rem x nb), by substitution
-    static const bool one_lane = getenv("LRN_POTRF_PANEL1") != nullptr;
-    static const bool eight_lanes = getenv("LRN_POTRF_PANEL8") != nullptr;   // (measurement: the round-3a kernel)
     if (one_lane || nb < NB)
       hipLaunchKernelGGL(potrf_panel_kernel, dim3((rem + 255) / 256), dim3(256), 0, st,
                          A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
@@ -524,6 +632,14 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
                          A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
     int rc;
     // trailing: A22 -= Wk Wk^T (lower tiles)
+    if (!use_gemm && nb == NB) {
+      const int nt = (rem + NB - 1) / NB;
+      const int fuse = (!no_fuse && !diag_wave) ? 1 : 0;
+      hipLaunchKernelGGL(potrf_syrk_kernel, dim3(nt, nt), dim3(256), 0, st, A + (long)(k0 + nb) + (long)(k0 + nb) * ld, ld,
+                         rem, work, info_dev, fuse, k0 + nb, diag0, boost, max_boost);
+      diag_done = fuse != 0;
+      continue;
+    }
     GemmDesc u;
     u.A = work; u.sAm = 1; u.sAk = rem;
     u.B = work; u.sBk = rem; u.sBn = 1;
