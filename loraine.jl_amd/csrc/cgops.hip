@@ -351,6 +351,106 @@ __global__ __launch_bounds__(256) void sp_dot_kernel(const long* __restrict__ pc
   }
 }
 
+// ---- the same operator for matrices that sit in L2 (msz < 1500: thetaG11, msz 801, 3 % of the entries of M stored) --
+// round 3.  There the dense route costs two msz^3 products and three passes over msz^2 (97 us per mat-vec at msz 801)
+// for 2 x 2 nnz(M) msz flop of useful work, and the kernels above -- one workgroup per column with a block reduction per
+// entry -- are bound by their serial loops.  Here: the gather and the symmetrisation in one launch (one thread per stored
+// entry, both halves of (M + M') / 2), and ONE WAVE per stored entry for Z[p, q] = W(:, p) . N(:, q).
+__global__ __launch_bounds__(256) void sp_gather_sym_kernel(const long* __restrict__ cq_ptr, const int* __restrict__ cq_j,
+                                                            const double* __restrict__ cq_v, const int* __restrict__ pc_t,
+                                                            long ncq, const double* __restrict__ x, double* __restrict__ Mv) {
+  // one wave per stored entry (a position can be shared by every constraint: thetaG11's corner entry by 1600)
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ncq) return;
+  const long u = pc_t[t];
+  double a = 0.0, b = 0.0;
+  for (long k = cq_ptr[t] + lane; k < cq_ptr[t + 1]; k += 64) a += cq_v[k] * x[cq_j[k]];
+  if (u != t)
+    for (long k = cq_ptr[u] + lane; k < cq_ptr[u + 1]; k += 64) b += cq_v[k] * x[cq_j[k]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+  // (raw[t] + raw[twin]) / 2 in a fixed order: the twins get the same bits
+  if (lane == 0) Mv[t] = (u == t) ? (a + a) / 2.0 : (t < u ? a + b : b + a) / 2.0;
+}
+
+// N[r, q] for 4 consecutive r per workgroup, one thread per q; the W values of up to 8 stored entries are requested
+// before they are used (one workgroup per CU at this size: nothing else hides the L2 latency).  Columns with more than
+// SP_LONG stored entries (thetaG11: one column of 801 among columns of 7) are left to sp_wm_long_kernel.
+static constexpr int SP_LONG = 64;
+__global__ __launch_bounds__(256) void sp_wm_small_kernel(const long* __restrict__ pc_ptr, const int* __restrict__ pc_r,
+                                                          const double* __restrict__ Mv, const double* __restrict__ W, int m,
+                                                          int q_lo, int q_hi, double* __restrict__ N) {
+  const int q = q_lo + blockIdx.y * 256 + threadIdx.x;
+  const int r0 = blockIdx.x * 4;
+  const bool live = q < q_hi;
+  const double* wq = W + (live ? q : q_lo);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + i;
+    if (r >= m) break;
+    const long t0 = pc_ptr[r], t1 = pc_ptr[r + 1];
+    if (t1 - t0 > SP_LONG) continue;
+    for (long t = t0; t < t1; t += 8) {
+      double w[8], v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool ok = t + k < t1;
+        v[k] = ok ? Mv[t + k] : 0.0;
+        w[k] = wq[(long)pc_r[ok ? t + k : t] * m];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[i] += v[k] * w[k];
+    }
+  }
+  if (!live) return;
+  double* dst = N + (long)q * m + r0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (r0 + i < m) {
+      const long cnt = pc_ptr[r0 + i + 1] - pc_ptr[r0 + i];
+      if (cnt <= SP_LONG) dst[i] = acc[i];
+    }
+}
+
+// N[r, q] of a long column r: one wave per q, the lanes over the stored entries (W(:, q) read at the rows of the
+// entries -- ascending, nearly contiguous)
+__global__ __launch_bounds__(256) void sp_wm_long_kernel(const long* __restrict__ pc_ptr, const int* __restrict__ pc_r,
+                                                         const double* __restrict__ Mv, const double* __restrict__ W, int m,
+                                                         int r, int q_lo, int q_hi, double* __restrict__ N) {
+  const int lane = threadIdx.x & 63;
+  const int q = q_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= q_hi) return;
+  const double* wq = W + (long)q * m;
+  double s = 0.0;
+  for (long t = pc_ptr[r] + lane; t < pc_ptr[r + 1]; t += 64) s += Mv[t] * wq[pc_r[t]];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) N[(long)q * m + r] = s;
+}
+
+__global__ __launch_bounds__(256) void sp_dot_wave_kernel(const long* __restrict__ cq_q, const int* __restrict__ pc_t, long ncq,
+                                                          const double* __restrict__ W, const double* __restrict__ N, int m,
+                                                          int q_lo, int q_hi, int mirror, double* __restrict__ Zs) {
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ncq) return;
+  const long key = cq_q[t];
+  const int q = (int)(key / m), p = (int)(key % m);
+  if (q < q_lo || q >= q_hi || (mirror && p > q)) return;
+  const double* wp = W + (long)p * m;
+  const double* nq = N + (long)q * m;
+  double s = 0.0;
+  for (int i = lane; i < m; i += 64) s += wp[i] * nq[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) {
+    Zs[t] = s;
+    if (mirror && p != q) Zs[pc_t[t]] = s;
+  }
+}
+
 // out[sigma[p]] -= sum_e a_e Zs[ent_t[e]]   (entries with column in [c_lo, c_hi))
 __global__ __launch_bounds__(256) void sp_aa_times_kernel(const long* __restrict__ ptr, const int* __restrict__ ec,
                                                           const double* __restrict__ ev, const int* __restrict__ ent_t,
@@ -372,9 +472,11 @@ __global__ __launch_bounds__(256) void sp_aa_times_kernel(const long* __restrict
 static bool use_sparse_matvec(const lrn_ctx* c, const LmiBlock& b) {
   if (!b.sp_ok || c->opt.matvec_sparse == 1) return false;
   if (c->opt.matvec_sparse == 2) return true;
-  // ~4e-12 ncq msz s against 4 msz^3 / 6e13 s; below msz ~ 1500 both are launch-bound and the GEMM path
-  // wins (thetaG11, msz = 801: 35 us per mat-vec)
-  return b.msz >= 1500 && (double)b.ncq * 60.0 < (double)b.msz * (double)b.msz;
+  // ~4e-12 ncq msz s against 4 msz^3 / 6e13 s.  Below msz ~ 1500 both routes are bound by their launches and L2: the
+  // wave-per-entry kernels win where a twelfth of M or less is stored
+  if (b.msz < 1500)
+    return b.msz >= 256 && (double)b.ncq * 12.0 < (double)b.msz * (double)b.msz && b.sp_long_cols.size() <= 4;
+  return (double)b.ncq * 60.0 < (double)b.msz * (double)b.msz;
 }
 
 // y += AA vec(W mat(AA'x) W) restricted to the pattern columns [q_lo, q_hi) of Z
@@ -383,15 +485,33 @@ static int matvec_sparse_block(lrn_ctx* c, LmiBlock& b, const double* x, double*
   hipStream_t st = c->stream;
   LRN_TRY(ensure(c, c->m1, (size_t)m * m * 8));
   double* N = c->m1.as<double>();
-  hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, st, b.cq_ptr.as<long>(),
-                     b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, b.Zs.as<double>());
-  hipLaunchKernelGGL(sp_symmetrize_kernel, dim3((unsigned)((b.ncq + 255) / 256)), dim3(256), 0, st, b.Zs.as<double>(),
-                     b.pc_t.as<int>(), b.ncq, b.Mv.as<double>());
+  const bool small = m < 1500;        // W and N sit in L2: one wave per stored entry (see sp_dot_wave_kernel)
+  if (small) {
+    hipLaunchKernelGGL(sp_gather_sym_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, st, b.cq_ptr.as<long>(),
+                       b.cq_j.as<int>(), b.cq_v.as<double>(), b.pc_t.as<int>(), b.ncq, x, b.Mv.as<double>());
+  } else {
+    hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, st, b.cq_ptr.as<long>(),
+                       b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, b.Zs.as<double>());
+    hipLaunchKernelGGL(sp_symmetrize_kernel, dim3((unsigned)((b.ncq + 255) / 256)), dim3(256), 0, st, b.Zs.as<double>(),
+                       b.pc_t.as<int>(), b.ncq, b.Mv.as<double>());
+  }
   if (q_hi > q_lo) {
-    hipLaunchKernelGGL(sp_wm_kernel, dim3((m + 15) / 16, (q_hi - q_lo + 255) / 256), dim3(256), 0, st, b.pc_ptr.as<long>(),
-                       b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, q_lo, q_hi, N);
-    hipLaunchKernelGGL(sp_dot_kernel, dim3(q_hi - q_lo), dim3(256), 0, st, b.pc_ptr.as<long>(), b.pc_r.as<int>(),
-                       b.pc_t.as<int>(), b.W.as<double>(), N, m, q_lo, mirror ? 1 : 0, b.Zs.as<double>());
+    if (small) {
+      hipLaunchKernelGGL(sp_wm_small_kernel, dim3((m + 3) / 4, (q_hi - q_lo + 255) / 256), dim3(256), 0, st,
+                         b.pc_ptr.as<long>(), b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, q_lo, q_hi, N);
+      for (int r : b.sp_long_cols)
+        hipLaunchKernelGGL(sp_wm_long_kernel, dim3((q_hi - q_lo + 3) / 4), dim3(256), 0, st, b.pc_ptr.as<long>(),
+                           b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, r, q_lo, q_hi, N);
+    } else {
+      hipLaunchKernelGGL(sp_wm_kernel, dim3((m + 15) / 16, (q_hi - q_lo + 255) / 256), dim3(256), 0, st, b.pc_ptr.as<long>(),
+                         b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, q_lo, q_hi, N);
+    }
+    if (small)
+      hipLaunchKernelGGL(sp_dot_wave_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, st, b.cq_q.as<long>(),
+                         b.pc_t.as<int>(), b.ncq, b.W.as<double>(), N, m, q_lo, q_hi, mirror ? 1 : 0, b.Zs.as<double>());
+    else
+      hipLaunchKernelGGL(sp_dot_kernel, dim3(q_hi - q_lo), dim3(256), 0, st, b.pc_ptr.as<long>(), b.pc_r.as<int>(),
+                         b.pc_t.as<int>(), b.W.as<double>(), N, m, q_lo, mirror ? 1 : 0, b.Zs.as<double>());
     hipLaunchKernelGGL(sp_aa_times_kernel, dim3((b.npos_nz + 3) / 4), dim3(256), 0, st, b.ent_ptr.as<long>(),
                        b.ent_c.as<int>(), b.ent_v.as<double>(), b.ent_t.as<int>(), b.Zs.as<double>(), q_lo, q_hi, b.npos_nz,
                        b.sigma_d.as<int>(), y);

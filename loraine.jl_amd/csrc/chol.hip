@@ -357,20 +357,30 @@ __global__ __launch_bounds__(256) void potrf_panel8_kernel(double* __restrict__ 
 // X_c L[c', c]' off on the MFMA (4 x v_mfma_f64_16x16x4 each).  Critical path per strip: 4 x (16-step chain + 4 MFMAs)
 // instead of the 8 x (36 + 64) dependent FMA / LDS pairs and 8 barriers of the eight-lane kernel above
 // (19 us at n = 800, 32 us at n = 4000).  No inverse of the diagonal sub-blocks: substitution, as everywhere in this file.
-__global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restrict__ A21, int ld, int rem,
-                                                               const double* __restrict__ Lkk, double* __restrict__ W,
+// General form: strip row r, column c of X at X[r * sr + c * sc] (the panel: sr = 1, sc = ld; the block rows of a matrix
+// right-hand side, one strip row per right-hand side: sr = ldb, sc = 1), a second copy at W[r * wr + c * wc]; nb < 64:
+// L_kk identity-padded; `reverse`: X L_kk = A instead of X L_kk' = A (columns and L_kk indexed from the end, which
+// makes it the same lower-triangular recurrence) -- the diagonal step of L' X = B.
+__global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restrict__ Xg, long sr, long sc, int nrows,
+                                                               const double* __restrict__ Lkk, int ld, int nb, int reverse,
+                                                               double* __restrict__ W, long wr, long wc,
                                                                const int* __restrict__ info) {
   __shared__ double Ls[NB][NB + 1];
   __shared__ double rinv[NB];
   __shared__ double Xs[4][16][NB + 1];
-  if (*info != 0) return;
+  if (info && *info != 0) return;
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   for (int e = t; e < NB * NB; e += 256) {
     const int i = e % NB, j = e / NB;
-    Ls[i][j] = i >= j ? Lkk[(long)i + (long)j * ld] : 0.0;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < nb && j < nb && i >= j) v = reverse ? Lkk[(long)(nb - 1 - j) + (long)(nb - 1 - i) * ld] : Lkk[(long)i + (long)j * ld];
+    Ls[i][j] = v;
   }
-  if (t < NB) rinv[t] = 1.0 / Lkk[(long)t + (long)t * ld];
+  if (t < NB) {
+    const int dgi = reverse ? nb - 1 - t : t;
+    rinv[t] = t < nb ? 1.0 / Lkk[(long)dgi + (long)dgi * ld] : 1.0;
+  }
   const int row0 = blockIdx.x * 64 + 16 * w;
   const int cr = lane >> 4, cc = lane & 15;
   v4f64 C[4];
@@ -378,11 +388,12 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
   for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = row0 + cr + 4 * r;
-      C[cb][r] = row < rem ? A21[(long)row + (long)(16 * cb + cc) * ld] : 0.0;
+      const int row = row0 + cr + 4 * r, col = 16 * cb + cc;
+      const int pc = reverse ? nb - 1 - col : col;
+      C[cb][r] = (row < nrows && col < nb) ? Xg[(long)row * sr + (long)pc * sc] : 0.0;
     }
   __syncthreads();
-  if (row0 >= rem) return;
+  if (row0 >= nrows) return;
   double (*X)[NB + 1] = Xs[w];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -410,14 +421,17 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
         C[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[c2], 0, 0, 0);
       }
   }
-  // the strip, rows fastest
+  // the strip, its memory-contiguous dimension along the lanes
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int row = row0 + cc, col = cr + 4 * i;
-    if (row < rem) {
-      const double v = X[cc][col];
-      A21[(long)row + (long)col * ld] = v;
-      W[(long)row + (long)col * rem] = v;
+    const int rl = (sr <= sc) ? cc : cr + 4 * (i & 3);          // strip row
+    const int col = (sr <= sc) ? cr + 4 * i : 16 * (i >> 2) + cc;
+    const int row = row0 + rl;
+    if (row < nrows && col < nb) {
+      const double v = X[rl][col];
+      const int pc = reverse ? nb - 1 - col : col;
+      Xg[(long)row * sr + (long)pc * sc] = v;
+      if (W) W[(long)row * wr + (long)pc * wc] = v;
     }
   }
 }
@@ -626,7 +640,7 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
                          A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
     else if (!eight_lanes)
       hipLaunchKernelGGL(potrf_panel_mfma_kernel, dim3((rem + 63) / 64), dim3(256), 0, st,
-                         A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
+                         A + (long)(k0 + nb) + (long)k0 * ld, 1L, (long)ld, rem, Akk, ld, NB, 0, work, 1L, (long)rem, info_dev);
     else
       hipLaunchKernelGGL(potrf_panel8_kernel, dim3((rem + 31) / 32), dim3(256), 0, st,
                          A + (long)(k0 + nb) + (long)k0 * ld, ld, rem, Akk, work, info_dev);
@@ -966,6 +980,14 @@ int trsm_left_lower(hipStream_t st, const double* L, int n, int ld, const double
     int b = trans ? nblk - 1 - bi : bi;
     int k0 = b * NB, nb = n - k0 < NB ? n - k0 : NB;
     // X_b = op(L_kk)^-1 B_b by substitution, one thread per right-hand side; tmp = X_b (NB x nrhs)
+    // X_b = op(L_kk)^-1 B_b: per right-hand side a row of the strip solve x L_kk' = b (x L_kk = b for the transposed
+    // system); nrhs >= 16: by strips of 16 right-hand sides on the MFMA (round 3: the one-thread-per-column kernel walks
+    // 2016 dependent FMA / LDS pairs, 53 us per block at nrhs = 801), else one thread per right-hand side
+    static const bool trsm_thread = getenv("LRN_TRSM_THREAD") != nullptr;
+    if (nrhs >= 16 && !trsm_thread)
+      hipLaunchKernelGGL(potrf_panel_mfma_kernel, dim3((nrhs + 63) / 64), dim3(256), 0, st, B + k0, (long)ldb, 1L, nrhs,
+                         L + (long)k0 + (long)k0 * ld, ld, nb, trans ? 1 : 0, tmp, (long)NB, 1L, (const int*)nullptr);
+    else
     hipLaunchKernelGGL(trsm_diag_kernel, dim3((nrhs + 255) / 256), dim3(256), 0, st,
                        L + (long)k0 + (long)k0 * ld, ld, nb, trans ? 1 : 0, B + k0, ldb, nrhs, tmp);
     int rc;

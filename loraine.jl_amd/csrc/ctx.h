@@ -33,6 +33,7 @@ struct LmiBlock {
   // sparsity pattern of mat(AA'x) = the stored columns above, when no constraint is stored dense and
   // the pattern is symmetric: sparse-aware mat-vec (cgops.hip, Z = W M W only where AA needs it)
   bool sp_ok = false;
+  std::vector<int> sp_long_cols;   // pattern columns with more than 64 stored entries (small-msz sparse mat-vec)
   lrn::DBuf pc_ptr;         // int64 [msz+1] pattern column -> range of stored columns
   lrn::DBuf pc_r;           // int32 [ncq] row of stored column t
   lrn::DBuf pc_t;           // int32 [ncq] stored column holding the transposed entry

@@ -350,6 +350,10 @@ extern "C" int lrn_upload_model(lrn_ctx* c, int nlmi, int nvar, const int64_t* m
           LRN_TRY(copy_in(c, b.pc_t.p, pt.data(), (size_t)nq * 4));
           LRN_TRY(copy_in(c, b.ent_t.p, et.data(), (size_t)b.nent * 4));
           b.sp_ok = true;
+          // columns of the pattern with many entries (sp_wm_long_kernel, cgops.hip)
+          b.sp_long_cols.clear();
+          for (long q = 0; q < m; ++q)
+            if (pcp[q + 1] - pcp[q] > 64) b.sp_long_cols.push_back((int)q);
         }
       }
     }
