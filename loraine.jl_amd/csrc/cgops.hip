@@ -183,6 +183,113 @@ __global__ __launch_bounds__(256) void aa_dense_dot_kernel(const double* __restr
   if (threadIdx.x == 0) out[sigma[blockIdx.x]] -= sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// ---- the passes over the dense constraint data at sizes where they are HBM streams (C4: 4000 matrices of 32 MB; round 3).
+// The one-element-per-thread kernels above keep one 8-byte load per lane in flight and re-read Z from the MALL for every
+// constraint (5.1 TB/s of constraint data, 25 ms per pass).  Here: 16-byte loads, eight of them in flight per lane, and FOUR
+// constraints per workgroup against one read of Z.  msz even (16-byte alignment of every matrix); else the kernels above.
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void aa_dense_dot4_kernel(const double* __restrict__ Ad, long mm, int nd,
+                                                            const double* __restrict__ Z, const int* __restrict__ sigma,
+                                                            double* __restrict__ out) {
+  __shared__ double sh[4][4];
+  const int p0 = blockIdx.x * 4;
+  const long n2 = mm >> 1;
+  const v2f64* z2 = reinterpret_cast<const v2f64*>(Z);
+  const v2f64* a2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a2[k] = reinterpret_cast<const v2f64*>(Ad + (long)(p0 + k < nd ? p0 + k : p0) * mm);
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  long q = threadIdx.x;
+  for (; q + 256 < n2; q += 512) {
+    const v2f64 z0 = z2[q], z1 = z2[q + 256];
+    v2f64 a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a0[k] = a2[k][q]; a1[k] = a2[k][q + 256]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += (a0[k].x * z0.x + a0[k].y * z0.y) + (a1[k].x * z1.x + a1[k].y * z1.y);
+  }
+  for (; q < n2; q += 256) {
+    const v2f64 z0 = z2[q];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const v2f64 a = a2[k][q]; s[k] += a.x * z0.x + a.y * z0.y; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && p0 + (int)threadIdx.x < nd) {
+    const int k = threadIdx.x;
+    out[sigma[p0 + k]] -= sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3];
+  }
+}
+
+// two products in one pass (aa_times2)
+__global__ __launch_bounds__(256) void aa_dense_dot4x2_kernel(const double* __restrict__ Ad, long mm, int nd,
+                                                              const double* __restrict__ Z1, const double* __restrict__ Z2,
+                                                              const int* __restrict__ sigma, double* __restrict__ out1,
+                                                              double* __restrict__ out2) {
+  __shared__ double sh[8][4];
+  const int p0 = blockIdx.x * 4;
+  const long n2 = mm >> 1;
+  const v2f64* y2 = reinterpret_cast<const v2f64*>(Z1);
+  const v2f64* z2 = reinterpret_cast<const v2f64*>(Z2);
+  const v2f64* a2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a2[k] = reinterpret_cast<const v2f64*>(Ad + (long)(p0 + k < nd ? p0 + k : p0) * mm);
+  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (long q = threadIdx.x; q < n2; q += 256) {
+    const v2f64 y0 = y2[q], z0 = z2[q];
+    v2f64 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = a2[k][q];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s[k] += a[k].x * y0.x + a[k].y * y0.y;
+      s[4 + k] += a[k].x * z0.x + a[k].y * z0.y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && p0 + (int)(threadIdx.x & 3) < nd) {
+    const int k = threadIdx.x;
+    const double v = sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3];
+    if (k < 4) out1[sigma[p0 + k]] -= v;
+    else out2[sigma[p0 + k - 4]] -= v;
+  }
+}
+
+// M[q] -= sum_p x[sigma[p]] Adense[p][q], two entries per lane, eight matrices in flight
+__global__ __launch_bounds__(256) void aat_dense2_kernel(const double* __restrict__ Ad, int nd, long mm,
+                                                         const int* __restrict__ sigma, const double* __restrict__ x,
+                                                         double* __restrict__ M) {
+  const long n2 = mm >> 1;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n2) return;
+  const v2f64* a2 = reinterpret_cast<const v2f64*>(Ad) + q;
+  v2f64 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
+  int p = 0;
+  for (; p + 8 <= nd; p += 8) {
+    v2f64 a[8];
+    double xs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = a2[(long)(p + k) * n2]; xs[k] = x[sigma[p + k]]; }
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) { s0 += xs[k] * a[k]; s1 += xs[k + 1] * a[k + 1]; }
+  }
+  for (; p < nd; ++p) s0 += x[sigma[p]] * a2[(long)p * n2];
+  v2f64* m2 = reinterpret_cast<v2f64*>(M) + q;
+  *m2 -= s0 + s1;
+}
+
 // row-sharded variants (multi-GPU mat-vec): only entries with r0 <= row < r1; Zg holds the rows
 // [r0,r1) of Z with leading dimension ldz
 __global__ __launch_bounds__(256) void aa_times_rows_kernel(const long* __restrict__ ptr, const int* __restrict__ er,
@@ -469,6 +576,12 @@ __global__ __launch_bounds__(256) void sp_aa_times_kernel(const long* __restrict
   if (lane == 0) out[sigma[p]] -= s;
 }
 
+// the 16-byte kernels of the dense passes: every matrix 16-byte aligned (msz even), enough data to be a stream
+static bool dense_stream_ok(const LmiBlock& b, const double* Z) {
+  static const bool off = getenv("LRN_DENSE_PASS_SCALAR") != nullptr;      // (measurement: the one-element-per-lane kernels)
+  return !off && (b.msz & 1) == 0 && b.msz >= 256 && (((uintptr_t)Z | (uintptr_t)b.Adense.p) & 15) == 0;
+}
+
 static bool use_sparse_matvec(const lrn_ctx* c, const LmiBlock& b) {
   if (!b.sp_ok || c->opt.matvec_sparse == 1) return false;
   if (c->opt.matvec_sparse == 2) return true;
@@ -570,14 +683,24 @@ int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
       p1 = std::min(b.nd, p0 + per);
       LRN_TRY(ensure(c, c->commvec, (size_t)c->nvar * 8));
       LRN_HIP(c, hipMemsetAsync(c->commvec.p, 0, (size_t)c->nvar * 8, c->stream));
-      if (p1 > p0)
+      if (p1 > p0) {
+        if (dense_stream_ok(b, Z))
+          hipLaunchKernelGGL(aa_dense_dot4_kernel, dim3((p1 - p0 + 3) / 4), dim3(256), 0, c->stream,
+                             b.Adense.as<double>() + (long)p0 * b.msz * b.msz, (long)b.msz * b.msz, p1 - p0, Z,
+                             b.sigma_d.as<int>() + p0, c->commvec.as<double>());
+        else
         hipLaunchKernelGGL(aa_dense_dot_kernel, dim3(p1 - p0), dim3(256), 0, c->stream,
                            b.Adense.as<double>() + (long)p0 * b.msz * b.msz, (long)b.msz * b.msz, Z, b.sigma_d.as<int>() + p0,
                            c->commvec.as<double>());
+      }
       LRN_TRY(comm_allreduce(c, c->commvec.as<double>(), c->nvar, 0));
       hipLaunchKernelGGL(vec_add_kernel, dim3(nb(c->nvar)), dim3(256), 0, c->stream, y, c->commvec.as<double>(), c->nvar);
       return LRN_OK;
     }
+    if (dense_stream_ok(b, Z))
+      hipLaunchKernelGGL(aa_dense_dot4_kernel, dim3((b.nd + 3) / 4), dim3(256), 0, c->stream, b.Adense.as<double>(),
+                         (long)b.msz * b.msz, b.nd, Z, b.sigma_d.as<int>(), y);
+    else
     hipLaunchKernelGGL(aa_dense_dot_kernel, dim3(b.nd), dim3(256), 0, c->stream, b.Adense.as<double>(),
                        (long)b.msz * b.msz, Z, b.sigma_d.as<int>(), y);
   }
@@ -615,6 +738,10 @@ int aa_times2(lrn_ctx* c, LmiBlock& b, const double* Z1, double* y1, const doubl
                          b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(), h ? Z2 : Z1, b.msz, b.nd, b.npos_nz,
                          b.sigma_d.as<int>(), h ? y2 : y1);
   }
+  if (dense_stream_ok(b, Z1) && dense_stream_ok(b, Z2))
+    hipLaunchKernelGGL(aa_dense_dot4x2_kernel, dim3((b.nd + 3) / 4), dim3(256), 0, c->stream, b.Adense.as<double>(),
+                       (long)b.msz * b.msz, b.nd, Z1, Z2, b.sigma_d.as<int>(), y1, y2);
+  else
   hipLaunchKernelGGL(aa_dense_dot2_kernel, dim3(b.nd), dim3(256), 0, c->stream, b.Adense.as<double>(), (long)b.msz * b.msz,
                      Z1, Z2, b.sigma_d.as<int>(), y1, y2);
   return LRN_OK;
@@ -636,12 +763,21 @@ int aat_to_mat(lrn_ctx* c, LmiBlock& b, const double* x, double* M) {
       LRN_TRY(ensure(c, c->commmat, (size_t)mm * 8));
       double* Tm = c->commmat.as<double>();
       LRN_HIP(c, hipMemsetAsync(Tm, 0, (size_t)mm * 8, c->stream));
-      if (p1 > p0)
+      if (p1 > p0) {
+        if (dense_stream_ok(b, Tm))
+          hipLaunchKernelGGL(aat_dense2_kernel, dim3((unsigned)((mm / 2 + 255) / 256)), dim3(256), 0, c->stream,
+                             b.Adense.as<double>() + (long)p0 * mm, p1 - p0, mm, b.sigma_d.as<int>() + p0, x, Tm);
+        else
         hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>() + (long)p0 * mm,
                            p1 - p0, mm, b.sigma_d.as<int>() + p0, x, Tm);
+      }
       LRN_TRY(comm_allreduce(c, Tm, mm, 0));
       hipLaunchKernelGGL(vec_add_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, Tm, mm);
     } else {
+      if (dense_stream_ok(b, M))
+        hipLaunchKernelGGL(aat_dense2_kernel, dim3((unsigned)((mm / 2 + 255) / 256)), dim3(256), 0, c->stream,
+                           b.Adense.as<double>(), b.nd, mm, b.sigma_d.as<int>(), x, M);
+      else
       hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>(), b.nd, mm,
                          b.sigma_d.as<int>(), x, M);
     }

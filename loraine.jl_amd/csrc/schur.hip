@@ -490,7 +490,8 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
   for (auto& rn : runs) p_elems = std::max(p_elems, (long)(m - rn.first) * (((rn.second - rn.first) + 15) & ~15));
   if (p_elems > 0) {
     long cap = c->opt.p_batch > 0 ? c->opt.p_batch : std::max<long>(16, (long)(8.6e9 / ((double)p_elems * 8.0)));
-    if (c->opt.p_batch <= 0 && c->world <= 1) cap = std::min<long>(cap, 256);
+    // one GPU: 256 matrices per launch, or what chol_path_applicable found room for (up to 1024)
+    if (c->opt.p_batch <= 0 && c->world <= 1) cap = std::max<long>(std::min<long>(cap, 256), std::min<long>(P_cap, 1024));
     P_cap = std::min<long>(std::min<long>(cap, nd), 32768);
   }
   LRN_TRY(ensure(c, c->P, (size_t)P_cap * std::max<long>(p_elems, 1) * 8));
