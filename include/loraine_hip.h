@@ -64,15 +64,18 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * the MFMA path), "profile" (0/1), "t_batch", "p_batch", "shard_bs" (0 = auto), "jacobi_warm" (0/1), "jacobi_block",
  * "jacobi_inner", "jacobi_wgs", "pivot_boost" (relative pivot level boosted in lrn_schur_factor, 0 = off),
  * "prec_eig" (0 auto / 1 full Jacobi eigendecomposition / 2 Lanczos extremes in lrn_prec_setup),
- * "matvec_sparse" (0 auto / 1 dense GEMM mat-vec / 2 pattern-restricted mat-vec when every
- * constraint is sparse),
+ * "matvec_sparse" (0 auto -- pattern-restricted mat-vec when every constraint is sparse and M = mat(AA'x) is sparse
+ * enough: msz >= 1500, or msz in [256, 1500) with at most 1/12 of M stored -- / 1 dense GEMM mat-vec / 2 pattern-restricted
+ * whenever every constraint is sparse),
  * "schur_chol" (dense Schur assembly through the Cholesky factor of W: -1 auto -- H_ij = <L'A_iL, L'A_jL> when
  * every constraint of the block is dense, T_k = L (L'A_kL) L' otherwise, both for msz >= 256 --,
  * 0 never (T_k = W A_k W), 1 as auto without the size threshold, 2 the T_k form only),
  * "schur_plan" (-1 decide locally / 0 / 1: the assembly path every rank of a sharded run agreed on, see lrn_schur_plan),
  * "gemm3_ksplit" (split-K factor of the inner-product GEMM, 0 = auto), "gemm3_sched" (1: regular and masked tiles of
- * GEMM3' in one launch, 0: two launches), "gemm3_tile" (0 auto / 128 / 160), "gemm_no_skip" (1: no block masks in the
- * three GEMMs of the factor path -- A/B switch), "gemm3_stagger" (experiment: K-walk stagger of the workgroups of
+ * GEMM3' in one launch, 0: two launches), "gemm3_tile" (0 auto / 128 / 160), "gemm3_strip" (1: nvar % 128 in (0, 32] -> the last
+ * 128 + nvar % 128 rows of H as a launch of 128 x 160 tiles instead of a row of edge tiles), "gemm_no_skip" (1: no block masks
+ * in the three GEMMs of the factor path -- A/B switch), "gemm_dyn_masks" (1: the masked K-steps of GEMM1'/2' branch per
+ * block as in round 2 -- A/B switch), "gemm3_stagger" (experiment: K-walk stagger of the workgroups of
  * GEMM3' in chunks of 16, 0 = off), "pair_lanes" (lanes per entry of the sparse pair kernel: 0 auto / 4 / 8 / 16 / 64),
  * "jacobi_cross" (1: cross-pair rotations only after round 0), "jacobi_early" (relative level below which a sweep's
  * rotations make it the last one; 0 = always run the confirming sweep), "eigmin_pair" (1: the two
