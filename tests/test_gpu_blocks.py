@@ -115,7 +115,7 @@ def test_gemm_packed_symmetric_dot(dev, m):
     assert relerr(H[mask], Href[mask]) < 1e-13
 
 
-@pytest.mark.parametrize("n", [1, 7, 64, 65, 104, 500, 1300])
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 104, 500, 1300, 2113])
 def test_potrf_potrs(dev, n):
     rng = np.random.default_rng(n)
     Mx = rng.standard_normal((n, n + 3))
@@ -157,6 +157,32 @@ def test_potrf_reports_not_pd(dev):
     A2 = np.full((5, 5), np.nan)
     _, info = dev.dbg_potrf(A2)
     assert info == 1
+
+
+@pytest.mark.parametrize("col", [0, 63, 64, 70, 199, 450])
+def test_potrf_failing_column_in_every_kind_of_block(dev, col):
+    """The first non-positive pivot is reported wherever it falls: in the first diagonal block (a launch of its own), at
+    the first column of a later block or inside it (factored by the tile (0, 0) workgroup of the trailing update, whose
+    straight-line pivot chain hands a panel with a bad pivot to the careful loop), in the ragged last block; and an exactly
+    singular matrix fails at the dependent column."""
+    rng = np.random.default_rng(11 + col)
+    n = 451
+    Mx = rng.standard_normal((n, n + 4))
+    A = Mx @ Mx.T + 0.5 * np.eye(n)
+    L0 = np.linalg.cholesky(A)
+    # make the pivot of column `col` negative: subtract more than the Schur complement's diagonal entry
+    A2 = A.copy()
+    A2[col, col] -= 1.01 * L0[col, col] ** 2
+    _, info = dev.dbg_potrf(A2)
+    assert info == col + 1
+    # exact rank deficiency: column `col` (> 0) a copy of column 0 -- the pivot is zero up to rounding, never accepted
+    # as a large positive number
+    if col > 0:
+        B = Mx[:, :n].copy()
+        B[col, :] = B[0, :]
+        A3 = B @ B.T
+        L, info = dev.dbg_potrf(A3)
+        assert info == col + 1 or (info == 0 and abs(np.tril(L)[col, col]) < 1e-6 * np.abs(np.diag(np.tril(L))).max())
 
 
 @pytest.mark.parametrize("n,nrhs,trans", [(50, 50, False), (300, 300, True), (801, 17, False), (130, 200, True)])

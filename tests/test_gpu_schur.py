@@ -578,6 +578,29 @@ def test_gemm3_tile_and_schedule_variants_agree(dev, nvar):
     assert relerr(Hs[0][:8, :8], np.tril(_brute_H(A, W))) < 1e-13
 
 
+@pytest.mark.parametrize("msz", [200, 300, 457])
+def test_gemm12_pattern_loops_equal_the_branch_per_block_kernel(dev, msz):
+    """GEMM1' / GEMM2' of the factor path: the K-steps with skipped blocks (triangular heads, edge tiles of msz % 128 != 0,
+    packed diagonal tiles) as straight-line loops per block pattern (round 3) against the round-2 body with a branch per
+    block (option gemm_dyn_masks).  A block outside the exact set multiplies stored zeros: bit-identical."""
+    nvar = 70
+    dev.synthetic_dense_model(msz, nvar, 45)
+    W, G = _spd(msz, 46)
+    dev.set_scaling(0, W, G)
+    dev.set_option("schur_chol", 1)
+    Hs = []
+    try:
+        for dyn in (0, 1):
+            dev.set_option("gemm_dyn_masks", dyn)
+            Hs.append(np.tril(dev.schur_assemble(0, want_H=True)))
+    finally:
+        dev.set_option("gemm_dyn_masks", 0)
+        dev.set_option("schur_chol", -1)
+    assert np.array_equal(Hs[0], Hs[1])
+    A = np.stack([dev.get_constraint(0, k) for k in range(6)])
+    assert relerr(Hs[0][:6, :6], np.tril(_brute_H(A, W))) < 1e-13
+
+
 @pytest.mark.parametrize("nvar", [416, 1050, 1056])
 def test_gemm3_last_tile_row_of_height_160(dev, nvar):
     """nvar % 128 in (0, 32]: the last 128 + nvar % 128 rows of H are tiled by 128 x 160 and one 160 x 160 tile on a second
