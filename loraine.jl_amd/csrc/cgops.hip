@@ -431,6 +431,50 @@ __global__ __launch_bounds__(256) void sp_wm_kernel(const long* __restrict__ pc_
     if (r0 + i < m) dst[i] = acc[i];
 }
 
+// The same product with the q-tiles dealt to the XCDs (round 3).  Above, blockIdx.x walks the row tiles, so the eight XCDs
+// work on the SAME 256 columns of W at a time and each of their L2s misses on the whole 20 MB slab (msz 10^4): 10.8 GB of
+// L2-miss traffic per mat-vec for 0.8 GB of W.  Here XCD x = blockIdx.x % 8 sweeps all row tiles of q-tile 8 (j / R) + x,
+// j = blockIdx.x / 8, 64 columns wide: the 64 x msz slab (5 MB) it gathers from -- every row 36 times at C5 -- stays in its
+// own L2.  One wave per 4 rows r, lanes over q (512-byte segments of W).
+__global__ __launch_bounds__(256) void sp_wm_xcd_kernel(const long* __restrict__ pc_ptr, const int* __restrict__ pc_r,
+                                                        const double* __restrict__ Mv, const double* __restrict__ W, int m,
+                                                        int q_lo, int q_hi, double* __restrict__ N) {
+  const int R = (m + 15) / 16, Q = (q_hi - q_lo + 63) / 64;
+  const int xcd = blockIdx.x & 7;
+  const long j = blockIdx.x >> 3;
+  const int qt = 8 * (int)(j / R) + xcd, rt = (int)(j % R);
+  if (qt >= Q) return;
+  const int lane = threadIdx.x & 63;
+  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = q_lo + qt * 64 + lane;
+  const bool live = q < q_hi;
+  const double* wq = W + (live ? q : q_lo);
+  const int r0 = rt * 16 + 4 * g;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + i;
+    if (r >= m) break;
+    const long t0 = pc_ptr[r], t1 = pc_ptr[r + 1];
+    for (long t = t0; t < t1; t += 4) {
+      double w[4], v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = t + k < t1;
+        v[k] = ok ? Mv[t + k] : 0.0;
+        w[k] = wq[(long)pc_r[ok ? t + k : t] * m];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[i] += v[k] * w[k];
+    }
+  }
+  if (!live) return;
+  double* dst = N + (long)q * m + r0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (r0 + i < m) dst[i] = acc[i];
+}
+
 // Zs[t] = W(:,p_t) . N(:,q_t) for the stored entries of pattern column q (one workgroup per column);
 // mirror: only p <= q is computed and copied to the transposed entry (Z is symmetric).
 __global__ __launch_bounds__(256) void sp_dot_kernel(const long* __restrict__ pc_ptr, const int* __restrict__ pc_r,
@@ -618,6 +662,12 @@ static int matvec_sparse_block(lrn_ctx* c, LmiBlock& b, const double* x, double*
         hipLaunchKernelGGL(sp_wm_long_kernel, dim3((q_hi - q_lo + 3) / 4), dim3(256), 0, st, b.pc_ptr.as<long>(),
                            b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, r, q_lo, q_hi, N);
     } else {
+      static const bool wm_plain = getenv("LRN_SP_WM_PLAIN") != nullptr;      // (measurement: the round-1 tiling)
+      const long R = (m + 15) / 16, Q8 = ((q_hi - q_lo + 63) / 64 + 7) / 8;
+      if (!wm_plain && 8 * Q8 * R < 0x7fffffffL)
+        hipLaunchKernelGGL(sp_wm_xcd_kernel, dim3((unsigned)(8 * Q8 * R)), dim3(256), 0, st, b.pc_ptr.as<long>(),
+                           b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, q_lo, q_hi, N);
+      else
       hipLaunchKernelGGL(sp_wm_kernel, dim3((m + 15) / 16, (q_hi - q_lo + 255) / 256), dim3(256), 0, st, b.pc_ptr.as<long>(),
                          b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, q_lo, q_hi, N);
     }
