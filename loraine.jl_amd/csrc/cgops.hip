@@ -671,7 +671,10 @@ static int matvec_sparse_block(lrn_ctx* c, LmiBlock& b, const double* x, double*
       hipLaunchKernelGGL(sp_wm_kernel, dim3((m + 15) / 16, (q_hi - q_lo + 255) / 256), dim3(256), 0, st, b.pc_ptr.as<long>(),
                          b.pc_r.as<int>(), b.Mv.as<double>(), b.W.as<double>(), m, q_lo, q_hi, N);
     }
-    if (small)
+    // one wave per stored entry at every size (round 3; C5: 1.74 -> 1.16 ms -- the workgroup-per-column kernel exposes the
+    // HBM latency at each of its entries: a block reduction and two barriers between one 80 KB column of W and the next)
+    static const bool dot_wg = getenv("LRN_SP_DOT_WG") != nullptr;           // (measurement: the round-1 kernel)
+    if (small || !dot_wg)
       hipLaunchKernelGGL(sp_dot_wave_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, st, b.cq_q.as<long>(),
                          b.pc_t.as<int>(), b.ncq, b.W.as<double>(), N, m, q_lo, q_hi, mirror ? 1 : 0, b.Zs.as<double>());
     else
