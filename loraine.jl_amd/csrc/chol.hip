@@ -127,8 +127,11 @@ __device__ __forceinline__ void rsqrt_pair(double p, double& sq, double& rinv) {
 
 // (M holds the block -- lower part, identity-padded beyond nb -- and bad_s = 0, visible to the whole workgroup on entry;
 // on return M holds the factor, or bad_s the failing column; ends with a barrier)
+// `leader` = false: a replica of the factorisation (potrf_step_kernel) -- the same arithmetic, boosted pivots included, but no
+// count of them (the leader's count decides) .
 __device__ __forceinline__ void diag_block_factor(double (*M)[NB + 1], int& bad_s, int nb, int col0, int* __restrict__ info,
-                                                  const double* __restrict__ diag0, double boost, int max_boost) {
+                                                  const double* __restrict__ diag0, double boost, int max_boost,
+                                                  bool leader = true) {
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   double d0v = 1.0;                              // wave 0, lane j: original diagonal entry of column col0 + j
@@ -181,7 +184,7 @@ __device__ __forceinline__ void diag_block_factor(double (*M)[NB + 1], int& bad_
               if (d0 > 0.0 && piv <= boost * d0 && piv == piv) {
                 piv = 1e40 * fmax(fabs(d0), 1.0);
                 int cnt = 0;
-                if (lane == 0) cnt = atomicAdd(info + 1, 1) + 1;
+                if (lane == 0 && leader) cnt = atomicAdd(info + 1, 1) + 1;
                 cnt = __builtin_amdgcn_readfirstlane(cnt);
                 if (cnt > max_boost) bad = col0 + j + 1;
               }
@@ -357,6 +360,40 @@ __global__ __launch_bounds__(256) void potrf_panel8_kernel(double* __restrict__ 
 // X_c L[c', c]' off on the MFMA (4 x v_mfma_f64_16x16x4 each).  Critical path per strip: 4 x (16-step chain + 4 MFMAs)
 // instead of the 8 x (36 + 64) dependent FMA / LDS pairs and 8 barriers of the eight-lane kernel above
 // (19 us at n = 800, 32 us at n = 4000).  No inverse of the diagonal sub-blocks: substitution, as everywhere in this file.
+// The solve of one 16 x 64 strip (see the kernel below): C = the strip as four MFMA-layout blocks, X = its LDS image (in / out:
+// the solved strip), Ls = L_kk (lower part read only), rinv = 1 / diag(L_kk).  One wave; LDS operations of one wave execute
+// in order, no barrier.
+__device__ __forceinline__ void strip_solve(v4f64 (&C)[4], double (*X)[NB + 1], double (*Ls)[NB + 1], const double* rinv,
+                                            int lane) {
+  const int cr = lane >> 4, cc = lane & 15;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[cr + 4 * r][16 * c + cc] = C[c][r];
+    if (lane < 16) {
+      double x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = X[lane][16 * c + k];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        x[j] *= rinv[16 * c + j];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) x[k] -= x[j] * Ls[16 * c + k][16 * c + j];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) X[lane][16 * c + k] = x[k];
+    }
+#pragma unroll
+    for (int c2 = c + 1; c2 < 4; ++c2)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double a = -X[cc][16 * c + 4 * kk + cr];
+        const double b = Ls[16 * c2 + cc][16 * c + 4 * kk + cr];
+        C[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[c2], 0, 0, 0);
+      }
+  }
+}
+
 // General form: strip row r, column c of X at X[r * sr + c * sc] (the panel: sr = 1, sc = ld; the block rows of a matrix
 // right-hand side, one strip row per right-hand side: sr = ldb, sc = 1), a second copy at W[r * wr + c * wc]; nb < 64:
 // L_kk identity-padded; `reverse`: X L_kk = A instead of X L_kk' = A (columns and L_kk indexed from the end, which
@@ -395,32 +432,7 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
   __syncthreads();
   if (row0 >= nrows) return;
   double (*X)[NB + 1] = Xs[w];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) X[cr + 4 * r][16 * c + cc] = C[c][r];
-    if (lane < 16) {
-      double x[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = X[lane][16 * c + k];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        x[j] *= rinv[16 * c + j];
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) x[k] -= x[j] * Ls[16 * c + k][16 * c + j];
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) X[lane][16 * c + k] = x[k];
-    }
-#pragma unroll
-    for (int c2 = c + 1; c2 < 4; ++c2)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double a = -X[cc][16 * c + 4 * kk + cr];
-        const double b = Ls[16 * c2 + cc][16 * c + 4 * kk + cr];
-        C[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, C[c2], 0, 0, 0);
-      }
-  }
+  strip_solve(C, X, Ls, rinv, lane);
   // the strip, its memory-contiguous dimension along the lanes
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -530,6 +542,141 @@ __global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ C,
     }
 }
 
+// One launch per block column (round 3): the trailing update with panel k, the factorisation of diagonal block k + 1 AND
+// the panel solve k + 1.  The workgroups of tile column 0 hold the rows of the next panel; each of them also forms tile
+// (0, 0) from the panel rows it has loaded anyway (64 more MFMAs per wave), factors it -- a replica of what the workgroup
+// of tile (0, 0) does, same arithmetic, same bits, no synchronisation between workgroups -- and solves its 64 rows by
+// strips (strip_solve) straight from the registers of the update: the panel never makes the round trip through memory as
+// an unsolved block, and the chain per block column is one kernel (update + 13 us of pivots + 4 x 16-step substitutions)
+// instead of two.  Wn: the next panel (rem - 64 rows, contiguous) -- a second work buffer, the update reads Wp.
+// The replicas must not read tile (0, 0) from A: the leader overwrites it with the factor, and a replica that is dispatched
+// late (two factorisations on two streams share the workgroup slots) would read L for A.  They read T00 (64 x 64,
+// contiguous), a copy of the tile that the workgroup of tile (1, 1) of the PREVIOUS step stored beside the matrix
+// (T00n: the copy this step's (1, 1) workgroup leaves for the next step; both in the slack of the panel buffers).
+__global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ C, int ld, int rem,
+                                                         const double* __restrict__ Wp, double* __restrict__ Wn,
+                                                         const double* __restrict__ T00, double* __restrict__ T00n,
+                                                         int* __restrict__ info, int col0, const double* __restrict__ diag0,
+                                                         double boost, int max_boost) {
+  constexpr int LS = NB + 8;
+  __shared__ double PA[NB][LS];
+  __shared__ double PB[NB][LS];
+  __shared__ double rinv[NB];
+  __shared__ int bad_s;
+  const int I = blockIdx.x, J = blockIdx.y;        // tile row / column of A22
+  if (J > I) return;
+  if (*info != 0) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int i0 = NB * I, j0 = NB * J;
+  const int cr = lane >> 4, cc = lane & 15;
+  const bool replica = (J == 0 && I > 0);          // this workgroup solves the rows i0 .. i0 + 63 of the next panel
+  v4f64 cv[4], acc[4], c00[4], a00[4];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 16 * bb + cc, j = j0 + 16 * w + cr + 4 * r;
+      cv[bb][r] = (i < rem && j < rem) ? C[(long)i + (long)j * ld] : 0.0;
+      acc[bb][r] = 0.0;
+      a00[bb][r] = 0.0;
+      c00[bb][r] = replica ? T00[(16 * bb + cc) + (16 * w + cr + 4 * r) * NB] : 0.0;               // (rem > 64 here)
+    }
+  {
+    const int row = t & 63, kq = t >> 6;
+    double va[16], vb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = kq + 4 * q;
+      va[q] = (j0 + row < rem) ? Wp[(long)(j0 + row) + (long)k * rem] : 0.0;
+      vb[q] = (I != J && i0 + row < rem) ? Wp[(long)(i0 + row) + (long)k * rem] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      PA[kq + 4 * q][row] = va[q];
+      if (I != J) PB[kq + 4 * q][row] = vb[q];
+    }
+  }
+  if (t == 0) bad_s = 0;
+  __syncthreads();
+  const double (*Pb)[LS] = (I != J) ? PB : PA;
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    const double a = PA[4 * kk + cr][16 * w + cc];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+      acc[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Pb[4 * kk + cr][16 * bb + cc], acc[bb], 0, 0, 0);
+    if (replica) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+        a00[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, PA[4 * kk + cr][16 * bb + cc], a00[bb], 0, 0, 0);
+    }
+  }
+  if (J > 0) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 16 * bb + cc, j = j0 + 16 * w + cr + 4 * r;
+        if (i < rem && j < rem) {
+          const double v = cv[bb][r] - acc[bb][r];
+          C[(long)i + (long)j * ld] = v;
+          if (I == 1 && J == 1) T00n[(i - NB) + (j - NB) * NB] = v;       // the next step's tile (0, 0), for its replicas
+        }
+      }
+    return;
+  }
+  // ---- tile column 0: the next diagonal block (I == 0: the leader, which stores it) and the next panel (I > 0)
+  const int nb = rem < NB ? rem : NB;
+  __syncthreads();                                 // (every wave is done with the panels)
+  double (*M)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(&PA[0][0]);
+  double (*Xs)[16][NB + 1] = reinterpret_cast<double (*)[16][NB + 1]>(&PB[0][0]);
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * bb + cc, j = 16 * w + cr + 4 * r;
+      const double d = replica ? c00[bb][r] - a00[bb][r] : cv[bb][r] - acc[bb][r];
+      M[i][j] = (i < nb && j < nb && i >= j) ? d : (i == j ? 1.0 : 0.0);
+      if (replica) Xs[bb][cc][j] = (i0 + i < rem) ? cv[bb][r] - acc[bb][r] : 0.0;       // row i of this tile, column j
+    }
+  __syncthreads();
+  diag_block_factor(M, bad_s, nb, col0, info, diag0, boost, max_boost, !replica);
+  if (bad_s) {
+    if (!replica && t == 0) atomicCAS(info, 0, bad_s);
+    return;
+  }
+  if (!replica) {
+    for (int e = t; e < NB * NB; e += 256) {
+      const int i = e % NB, j = e / NB;
+      if (i < nb && j < nb && i >= j) C[(long)i + (long)j * ld] = M[i][j];
+    }
+    return;
+  }
+  if (t < NB) rinv[t] = 1.0 / M[t][t];
+  __syncthreads();
+  {
+    // strip w of this tile: rows i0 + 16 w .. + 15, against the factor just computed
+    double (*X)[NB + 1] = Xs[w];
+    v4f64 S[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[cb][r] = X[cr + 4 * r][16 * cb + cc];
+    strip_solve(S, X, M, rinv, lane);
+    const int remn = rem - NB;                     // rows of the next panel
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = i0 + 16 * w + cc, col = cr + 4 * q;
+      if (row < rem) {
+        const double v = X[cc][col];
+        C[(long)row + (long)col * ld] = v;
+        Wn[(long)(row - NB) + (long)col * remn] = v;
+      }
+    }
+  }
+}
+
 // Diagonal step of the matrix solves: X_b = L_kk^-1 B_b (trans = 0) or L_kk^-T B_b (trans = 1) for the
 // block rows [k0, k0 + nb) of B (ldb), one thread per right-hand side; result in place and in
 // tmp (NB x nrhs, ld NB).
@@ -618,6 +765,32 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
   static const bool eight_lanes = getenv("LRN_POTRF_PANEL8") != nullptr;    // (measurement: the round-3a kernel)
   static const bool use_gemm = getenv("LRN_POTRF_GEMM") != nullptr;         // (measurement: the general GEMM, as in round 2)
   static const bool no_fuse = getenv("LRN_POTRF_NOFUSE") != nullptr;        // (measurement: diagonal blocks as launches of their own)
+  static const bool no_step = getenv("LRN_POTRF_NOSTEP") != nullptr;        // (measurement: diagonal + panel + update kernels)
+  if (!no_step && !diag_wave && !one_lane && !eight_lanes && !use_gemm && !no_fuse && Linv && n > NB) {
+    // one launch per block column (potrf_step_kernel); the panels alternate between `work` and `Linv` (n x NB doubles each)
+    hipLaunchKernelGGL(potrf_diag_blk_kernel, dim3(1), dim3(256), 0, st, A, ld, NB, 0, info_dev, diag0, boost, max_boost);
+    double* cur = work;
+    hipLaunchKernelGGL(potrf_panel_mfma_kernel, dim3((n - NB + 63) / 64), dim3(256), 0, st, A + NB, 1L, (long)ld, n - NB, A, ld,
+                       NB, 0, cur, 1L, (long)(n - NB), info_dev);
+    // the copies of the next diagonal tile live behind the largest panel a buffer can hold: (n - NB) x NB doubles of
+    // n x NB (work) / >= n x NB (Linv)
+    const size_t t00_off = (size_t)(n - NB) * NB;
+    {
+      const int e0 = n - NB < NB ? n - NB : NB;        // tile (0, 0) of the first trailing matrix, as it is in A
+      if (hipMemcpy2DAsync(cur + t00_off, (size_t)NB * 8, A + (long)NB + (long)NB * ld, (size_t)ld * 8, (size_t)e0 * 8, e0,
+                           hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return LRN_ERR_HIP;
+    }
+    for (int k0 = 0; n - k0 - NB > 0; k0 += NB) {
+      const int rem = n - k0 - NB;
+      const int nt = (rem + NB - 1) / NB;
+      double* nxt = (cur == work) ? Linv : work;
+      hipLaunchKernelGGL(potrf_step_kernel, dim3(nt, nt), dim3(256), 0, st, A + (long)(k0 + NB) + (long)(k0 + NB) * ld, ld,
+                         rem, cur, nxt, cur + t00_off, nxt + t00_off, info_dev, k0 + NB, diag0, boost, max_boost);
+      cur = nxt;
+    }
+    return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
   bool diag_done = false;                 // the diagonal block of this step was factored by the previous update kernel
   for (int b = 0; b < nblk; ++b) {
     int k0 = b * NB;

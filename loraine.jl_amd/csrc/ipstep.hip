@@ -1106,7 +1106,7 @@ extern "C" int lrn_dbg_get_block(lrn_ctx* c, int il, const char* name, double* o
   struct { const char* n; DBuf* d; size_t bytes; } tab[] = {
       {"W", &b.W, mm_}, {"Si", &b.Si, mm_}, {"G", &b.G, mm_}, {"Gi", &b.Gi, mm_}, {"D", &b.D, mv}, {"DDsi", &b.DDsi, mv},
       {"X", &b.X, mm_}, {"S", &b.S, mm_}, {"delX", &b.delX, mm_}, {"delS", &b.delS, mm_}, {"RNT", &b.RNT, mm_},
-      {"LX", &b.LXf, mm_}, {"Bs", &b.Bs, mm_}, {"TX", &b.TX, mm_}, {"Ki", &b.Ki, mm_}, {"Yh", &b.Yh, mm_},
+      {"LX", &b.LXf, mm_}, {"LS", &b.LSf, mm_}, {"Bs", &b.Bs, mm_}, {"TX", &b.TX, mm_}, {"Ki", &b.Ki, mm_}, {"Yh", &b.Yh, mm_},
       {"Zh", &b.Zh, mm_}, {"Qm", &b.Qm, mm_}};
   if (flag) *flag = b.nt_free ? 1 : 0;
   c->timing["ns_c"] = b.ns_c;

@@ -203,3 +203,33 @@ def test_probes(dev):
     gb = dev.hbm_copy_peak(1 << 30)
     print(f"FP64 MFMA issue-rate probe: {tf:.1f} TFLOP/s ; HBM copy: {gb:.0f} GB/s")
     assert tf > 10 and gb > 500
+
+
+@pytest.mark.parametrize("n", [1500, 3000])
+def test_two_factorisations_side_by_side_on_two_streams(dev, n):
+    """cholesky(X) and cholesky(S) of the NT scaling run on two streams: their workgroups share the slots of the chip, so
+    the replicas of a diagonal block (potrf_step_kernel) can start after the leader has stored the factor over the tile --
+    they must read their copy of it, not the matrix.  Same bits as one after the other, and LAPACK's factor."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n)
+    def spd():
+        Mx = rng.standard_normal((n, n + 7)) / np.sqrt(n)
+        return Mx @ Mx.T + 0.05 * np.eye(n)
+    X, S = spd(), spd()
+    nvar = 4
+    AA = sp.csc_matrix((np.ones(nvar), (np.arange(nvar), np.arange(nvar) * (n + 1))), shape=(nvar, n * n))
+    dev.upload_model([AA], np.arange(nvar, dtype=np.int64).reshape(-1, 1), np.zeros((2, 1), dtype=np.int64), [n])
+    dev.ip_set_c(0, np.eye(n))
+    got = {}
+    try:
+        for streams in (1, 0, 1):
+            dev.set_option("prepw_streams", streams)
+            dev.ip_set_iterate(0, X, S)
+            assert dev.ip_prepare_w(0) == 0
+            got.setdefault(streams, []).append((np.tril(dev.dbg_get_block(0, "LX")[0]), np.tril(dev.dbg_get_block(0, "LS")[0])))
+    finally:
+        dev.set_option("prepw_streams", 1)
+    (lx1, ls1), (lx1b, ls1b) = got[1]
+    lx0, ls0 = got[0][0]
+    assert np.array_equal(lx1, lx0) and np.array_equal(ls1, ls0) and np.array_equal(lx1b, lx0) and np.array_equal(ls1b, ls0)
+    assert relerr(lx0, np.linalg.cholesky(X)) < 1e-11 and relerr(ls0, np.linalg.cholesky(S)) < 1e-11
