@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DENSE_MSZ = 256      # even and >= 256: the 16-byte kernels of the passes over dense constraint data run, rank by rank
 
 
 def _free_port():
@@ -50,7 +51,7 @@ def _worker(rank, world, port, out_dir):
         dev.comm_destroy()
     # dense data: the Cholesky path splits the columns of the matrix variable, the exchange is an all-reduce
     dev.set_option("schur_chol", 1)            # (auto takes the path from msz 256 on)
-    solver, ha = synthetic_dense_solver(dev, 96, 160, seed=11, options=dict(kit=0, verb=0))
+    solver, ha = synthetic_dense_solver(dev, DENSE_MSZ, 160, seed=11, options=dict(kit=0, verb=0))
     hot = DistributedHotPath(solver, rank, world)
     solver.solve(ha)
     out["dense"] = dict(status=solver.status, iters=solver.iter, obj=float(solver.primal_obj),
@@ -83,7 +84,7 @@ def test_two_ranks_on_one_gpu_solve_through_the_library_communicator(tmp_path):
     from loraine_jl_amd.synthetic import synthetic_dense_solver
     dev = loraine_jl_amd.Device(0)
     dev.set_option("schur_chol", 1)
-    solver, ha = synthetic_dense_solver(dev, 96, 160, seed=11, options=dict(kit=0, verb=0))
+    solver, ha = synthetic_dense_solver(dev, DENSE_MSZ, 160, seed=11, options=dict(kit=0, verb=0))
     solver.solve(ha)
     dev.close()
     assert solver.status == 1 and solver.iter == r[0]["dense"]["iters"]
