@@ -28,7 +28,8 @@ for cfg in ("c5", "c3"):
     rows.sort(reverse=True)
     out += rows[:14]
 os.makedirs("profiles", exist_ok=True)
-with open("profiles/r01_kit1_hbm_traffic.csv", "w", newline="") as fh:
+OUT = os.environ.get("KIT1_OUT", "gpurun_out/kit1_hbm_traffic.csv")
+with open(OUT, "w", newline="") as fh:
     w = csv.writer(fh)
     w.writerow(["config", "kernel", "launches", "avg_us", "FETCH_SIZE_MB_raw", "WRITE_SIZE_MB_raw", "hbm_MB_per_launch(2F+W)", "hbm_GB_per_s"])
     for r in out:

@@ -9,11 +9,12 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 for cnt in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $O/pmc_c5_$cnt $O/pmc_c3_$cnt
   echo "== C5 $cnt"
-  rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_c5_$cnt -- python3 tools/c5_solve.py 10000 20000 4 2 > $O/pmc_c5_$cnt.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_c5_$cnt -- python3 tools/c5_solve.py 10000 20000 4 2 > $O/pmc_c5_$cnt.log 2>&1
   tail -1 $O/pmc_c5_$cnt.log | cut -c1-200
   echo "== C3 $cnt"
-  rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_c3_$cnt -- python3 tools/e2e_times.py thetaG11 > $O/pmc_c3_$cnt.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $O/pmc_c3_$cnt -- python3 tools/e2e_times.py --nocpu thetaG11 > $O/pmc_c3_$cnt.log 2>&1
   tail -1 $O/pmc_c3_$cnt.log | cut -c1-200
 done
 python3 tools/pmc_kit1_summary.py
