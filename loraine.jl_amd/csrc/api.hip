@@ -60,6 +60,9 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->ezbuf);
   release(c->commvec);
   release(c->commmat);
+  release(c->hopbuf);
+  if (c->pin) (void)hipHostFree(c->pin);
+  for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   if (c->evA) (void)hipEventDestroy(c->evA);
@@ -101,6 +104,9 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "jacobi_inner")) c->opt.jacobi_inner = (int)value;
   else if (!strcmp(key, "pair_lanes")) c->opt.pair_lanes = (int)value;
   else if (!strcmp(key, "matvec_sparse")) c->opt.matvec_sparse = (int)value;
+  else if (!strcmp(key, "matvec_h")) { c->opt.matvec_h = (int)value; c->hop_version = -1; }
+  else if (!strcmp(key, "comm_fail_ensure")) lrn::comm_inject_ensure_failure(c);      // test hook (tests/test_gpu_comm.py)
+  else if (!strcmp(key, "pcg_lookahead")) c->opt.pcg_lookahead = std::max(0, std::min(8, (int)value));
   else if (!strcmp(key, "jacobi_cross")) c->opt.jacobi_cross = (int)value;
   else if (!strcmp(key, "jacobi_early")) c->opt.jacobi_early = value;
   else if (!strcmp(key, "eigmin_pair")) c->opt.eigmin_pair = (int)value;
@@ -126,6 +132,8 @@ int lrn_set_shard(lrn_ctx* c, int rank, int world) {
   c->rank = rank;
   c->world = world;
   lrn::update_shard_bs(c);
+  c->hop_version = -1;        // the operator choice and an H assembled under another sharding do not carry over
+  c->H_version = -1;
   return LRN_OK;
 }
 
@@ -139,6 +147,7 @@ int lrn_set_scaling(lrn_ctx* c, int il, const double* W, const double* G) {
   b.have_W = true;
   b.have_G = false;
   b.nt_free = false;
+  c->scal_version += 1;
   if (G) {
     LRN_TRY(copy_in(c, b.G.p, G, mm));
     b.have_G = true;
@@ -161,6 +170,7 @@ int lrn_set_lin(lrn_ctx* c, const double* X_lin, const double* S_lin_inv) {
     memcpy(s.data(), S_lin_inv, (size_t)c->nlin * 8);
   }
   for (int i = 0; i < c->nlin; ++i) x[i] *= s[i];
+  c->scal_version += 1;
   return copy_in(c, c->lin_xs.p, x.data(), (size_t)c->nlin * 8);
 }
 
@@ -244,6 +254,7 @@ int lrn_schur_import_full(lrn_ctx* c, const double* buf) {
   c->H_partial = false;
   c->H_shifted = false;
   c->have_L = false;
+  c->H_version = -1;          // (an imported matrix: the library does not know which scaling it belongs to)
   return LRN_OK;
 }
 

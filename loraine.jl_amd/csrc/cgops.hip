@@ -928,10 +928,16 @@ __global__ __launch_bounds__(1024) void cg_norm_kernel(const double* __restrict_
   if (threadIdx.x == 0) scal[slot] = s;
 }
 
+// scal[8] = exit code once the iteration has ended (30 converged, -13 alpha invalid), scal[9] = the iteration it ended
+// in: the host queues iterations ahead of the convergence test it has read (option pcg_lookahead); the kernels of the
+// iterations queued beyond the last one find the flag set and leave x, r, p alone -- the iteration count and the
+// result are those of the loop that tests after every step (ConjugateGradients.jl)
 __global__ __launch_bounds__(1024) void cg_alpha_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
                                                         const double* __restrict__ z, double* __restrict__ r,
-                                                        double* __restrict__ x, int n, double* __restrict__ scal) {
+                                                        double* __restrict__ x, int n, double* __restrict__ scal, int it,
+                                                        double res0, double tol) {
   __shared__ double sh[16];
+  if (scal[8] != 0.0) return;
   double g = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) { g += r[i] * z[i]; q += p[i] * Ap[i]; }
   g = wg_sum1024(g, sh);
@@ -947,12 +953,17 @@ __global__ __launch_bounds__(1024) void cg_alpha_kernel(const double* __restrict
       rr += ri * ri;
     }
   rr = wg_sum1024(rr, sh);
-  if (threadIdx.x == 0) { scal[0] = g; scal[1] = q; scal[2] = alpha; scal[3] = rr; scal[4] = bad ? 1.0 : 0.0; }
+  if (threadIdx.x == 0) {
+    scal[0] = g; scal[1] = q; scal[2] = alpha; scal[3] = rr; scal[4] = bad ? 1.0 : 0.0;
+    if (bad) { scal[8] = -13.0; scal[9] = (double)it; }
+    else if (sqrt(rr) / res0 <= tol) { scal[8] = 30.0; scal[9] = (double)it; }
+  }
 }
 
 __global__ __launch_bounds__(1024) void cg_beta_kernel(const double* __restrict__ z, const double* __restrict__ r,
                                                        double* __restrict__ p, int n, double* __restrict__ scal) {
   __shared__ double sh[16];
+  if (scal[8] != 0.0) return;
   double zr = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) zr += z[i] * r[i];
   zr = wg_sum1024(zr, sh);
@@ -1370,6 +1381,51 @@ int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
   return LRN_OK;
 }
 
+// Which operator serves this NT scaling: the assembled Schur matrix (hop.hip) or the matrix-free MyA.  Decided once per
+// scaling from the static cost model and the CG iterations of the previous scaling; with a communicator the ranks take
+// the decision together (free memory and so the assembly path can differ between them).
+int op_select(lrn_ctx* c, bool* use_h) {
+  if (c->hop_version != c->scal_version) {
+    c->cg_prev_iters = c->cg_cur_iters;
+    c->cg_cur_iters = 0;
+    bool use = hop_worthwhile(c, c->cg_prev_iters);
+    if (c->comm && c->world > 1) {
+      double w[1] = {use ? 0.0 : 1.0};
+      LRN_TRY(comm_status_max(c, w, 1));
+      use = w[0] == 0.0;
+    }
+    c->hop_use = use;
+    c->hop_version = c->scal_version;
+  }
+  if (c->hop_use) {
+    const int rc = hop_prepare(c);
+    if (rc != LRN_OK) {
+      if (c->comm && c->world > 1) return rc;       // (every rank returns it: the status reduction of the exchange)
+      c->hop_use = false;                            // one GPU: the matrix-free operator needs no workspace
+      c->counts["hop_fallback"] += 1;
+      c->err.clear();
+    }
+  }
+  *use_h = c->hop_use;
+  return LRN_OK;
+}
+
+// Ap = A p by the selected operator (all-reduced when sharded)
+static int op_apply(lrn_ctx* c, bool use_h, const double* p, double* Ap) {
+  const bool sharded = c->comm && c->world > 1;
+  if (use_h) {
+    LRN_TRY(hop_apply(c, p, Ap));
+  } else if (sharded) {
+    // one process per GPU: this rank's rows of W M W, then ONE all-reduce of the nvar-vector on this stream -- the
+    // recurrence is replicated and stays on the device, as on one GPU
+    LRN_TRY(matvec_partial_dev(c, p, Ap, c->rank, c->world));
+  } else {
+    return matvec_dev(c, p, Ap);
+  }
+  if (sharded) LRN_TRY(comm_allreduce(c, Ap, c->nvar, 0));
+  return LRN_OK;
+}
+
 // cg(A, b; tol, maxIter, precon) -- restates ConjugateGradients.jl 0.1 (see oracle.cg)
 int pcg_dev(lrn_ctx* c, const double* b, double tol, int maxit, double* x, int* exit_code, int* iters) {
   const int n = c->nvar;
@@ -1381,9 +1437,14 @@ int pcg_dev(lrn_ctx* c, const double* b, double tol, int maxit, double* x, int* 
   double* Ap = p + n;
   double* tmpv = Ap + n;
   double* scal = tmpv + n;          // 16 doubles
-  double hs[8];
+  constexpr int NSLOT = 16;
+  if (!c->pin) LRN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin), NSLOT * 16 * 8, hipHostMallocDefault));
+  if (!c->pcg_ev[0])
+    for (int i = 0; i < NSLOT; ++i) LRN_HIP(c, hipEventCreateWithFlags(&c->pcg_ev[i], hipEventDisableTiming));
+  double* hs = c->pin;
   long nmv = 0;
   LRN_HIP(c, hipMemsetAsync(x, 0, (size_t)n * 8, st));
+  LRN_HIP(c, hipMemsetAsync(scal, 0, 16 * 8, st));
   hipLaunchKernelGGL(cg_norm_kernel, dim3(1), dim3(1024), 0, st, b, n, scal, 6);
   LRN_HIP(c, hipMemcpyAsync(hs, scal + 6, 8, hipMemcpyDeviceToHost, st));
   LRN_HIP(c, hipStreamSynchronize(st));
@@ -1392,31 +1453,40 @@ int pcg_dev(lrn_ctx* c, const double* b, double tol, int maxit, double* x, int* 
   LRN_HIP(c, hipMemcpyAsync(r, b, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   const double residual_0 = std::sqrt(hs[0]);
   if (residual_0 <= tol) { *exit_code = 2; *iters = 0; return LRN_OK; }
+  bool use_h = false;
+  LRN_TRY(op_select(c, &use_h));
   LRN_TRY(prec_apply_dev(c, r, z, tmpv));
   LRN_HIP(c, hipMemcpyAsync(p, z, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-  const bool sharded = c->comm && c->world > 1;
-  for (int it = 1; it <= maxit; ++it) {
-    if (sharded) {
-      // one process per GPU: this rank's rows of W M W, then ONE all-reduce of the nvar-vector on this stream -- the
-      // recurrence below is replicated and stays on the device, as on one GPU
-      LRN_TRY(matvec_partial_dev(c, p, Ap, c->rank, c->world));
-      LRN_TRY(comm_allreduce(c, Ap, n, 0));
-    } else {
-      LRN_TRY(matvec_dev(c, p, Ap));
-    }
+  // The host runs `ahead` iterations in front of the convergence test it has read: the words of iteration `it` are
+  // copied to pinned memory behind its cg_alpha_kernel and looked at while iteration it + ahead is being queued.
+  const int ahead = std::max(0, std::min(NSLOT - 2, c->opt.pcg_lookahead));
+  int done_code = 0, done_it = 0;
+  auto poll = [&](int it) -> int {          // the words of iteration `it`
+    const int s = it % NSLOT;
+    LRN_HIP(c, hipEventSynchronize(c->pcg_ev[s]));
+    if (hs[s * 16 + 8] != 0.0) { done_code = (int)hs[s * 16 + 8]; done_it = (int)hs[s * 16 + 9]; }
+    return LRN_OK;
+  };
+  int it = 1;
+  for (; it <= maxit && done_code == 0; ++it) {
+    LRN_TRY(op_apply(c, use_h, p, Ap));
     ++nmv;
-    hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1024), 0, st, p, Ap, z, r, x, n, scal);
-    LRN_HIP(c, hipMemcpyAsync(hs, scal, 5 * 8, hipMemcpyDeviceToHost, st));
-    LRN_HIP(c, hipStreamSynchronize(st));
-    if (hs[4] != 0.0) { *exit_code = -13; *iters = it; c->counts["matvec"] += nmv; return LRN_OK; }
-    double residual = std::sqrt(hs[3]) / residual_0;
-    if (residual <= tol) { *exit_code = 30; *iters = it; c->counts["matvec"] += nmv; return LRN_OK; }
+    hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1024), 0, st, p, Ap, z, r, x, n, scal, it, residual_0, tol);
+    const int s = it % NSLOT;
+    LRN_HIP(c, hipMemcpyAsync(hs + s * 16, scal, 10 * 8, hipMemcpyDeviceToHost, st));
+    LRN_HIP(c, hipEventRecord(c->pcg_ev[s], st));
+    if (it - ahead >= 1) LRN_TRY(poll(it - ahead));
+    if (done_code != 0) break;
     LRN_TRY(prec_apply_dev(c, r, z, tmpv));
     hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1024), 0, st, z, r, p, n, scal);
   }
-  *exit_code = -2;
-  *iters = maxit;
+  const int last = std::min(it, maxit);
+  for (int k = std::max(1, last - ahead + 1); k <= last && done_code == 0; ++k) LRN_TRY(poll(k));
+  LRN_HIP(c, hipStreamSynchronize(st));
   c->counts["matvec"] += nmv;
+  if (done_code != 0) { *exit_code = done_code; *iters = done_it; }
+  else { *exit_code = -2; *iters = maxit; }
+  c->cg_cur_iters += *iters;
   return LRN_OK;
 }
 
@@ -1429,13 +1499,11 @@ extern "C" int lrn_matvec(lrn_ctx* c, const double* x, double* Ax) {
   LRN_HIP(c, hipSetDevice(c->device));
   const int n = c->nvar;
   LRN_TRY(copy_in(c, c->v0.p, x, (size_t)n * 8));
+  // the assembled-matrix operator only when lrn_pcg chose it for this scaling, or when it is forced (option matvec_h = 2)
+  bool use_h = false;
+  if (c->opt.matvec_h == 2 || (c->hop_use && c->hop_version == c->scal_version)) LRN_TRY(op_select(c, &use_h));
   tic(c);
-  if (c->comm && c->world > 1) {
-    LRN_TRY(matvec_partial_dev(c, c->v0.as<double>(), c->v1.as<double>(), c->rank, c->world));
-    LRN_TRY(comm_allreduce(c, c->v1.as<double>(), n, 0));
-  } else {
-    LRN_TRY(matvec_dev(c, c->v0.as<double>(), c->v1.as<double>()));
-  }
+  LRN_TRY(op_apply(c, use_h, c->v0.as<double>(), c->v1.as<double>()));
   toc(c, "matvec");
   return copy_out(c, Ax, c->v1.p, (size_t)n * 8);
 }

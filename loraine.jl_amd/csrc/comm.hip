@@ -27,7 +27,12 @@ struct Comm {
   DBuf gathered;
   DBuf flags;      // small device buffer for status words
   long calls = 0;
+  bool fail_next_ensure = false;   // test hook (option "comm_fail_ensure"): the next exchange fails its buffer allocation
 };
+
+void comm_inject_ensure_failure(lrn_ctx* c) {
+  if (c->comm) c->comm->fail_next_ensure = true;
+}
 
 static int nccl_fail(lrn_ctx* c, ncclResult_t r, const char* what) {
   return set_error(c, LRN_ERR_HIP, "%s failed: %s", what, ncclGetErrorString(r));
@@ -109,33 +114,48 @@ __global__ void unpack_lower_kernel(const double* __restrict__ buf, int n, doubl
 // The exchange after an assembly on this context's communicator.  `rc_local` is what the local assembly returned:
 // every rank enters the status reduction whatever happened to it, so a rank that failed (out of memory, a W that could
 // not be factored where the others could) makes ALL ranks return an error instead of leaving its peers in a collective.
-int comm_schur_exchange(lrn_ctx* c, int rc_local) {
+int comm_schur_exchange(lrn_ctx* c, int rc_local, bool gather_blocks) {
   Comm* m = c->comm;
   if (!m || m->world <= 1) return rc_local;
   const int n = c->nvar;
-  double w[3] = {rc_local == LRN_OK ? 0.0 : 1.0, c->H_partial ? 1.0 : 0.0, c->H_partial ? 0.0 : 1.0};
+  // The exchange buffers are allocated BEFORE the status reduction and their failure is part of the status word: a rank
+  // that cannot allocate them must not return while its peers enter the collective below.
+  const long np = (long)n * (n + 1) / 2;
+  const long per = (long)lrn_schur_shard_doubles(c);
+  int rc_buf = LRN_OK;
+  if (rc_local == LRN_OK) {
+    if (m->fail_next_ensure) { m->fail_next_ensure = false; rc_buf = set_error(c, LRN_ERR_NOMEM, "exchange buffers: injected allocation failure (test)"); }
+    else if (c->H_partial) rc_buf = ensure(c, m->pack, (size_t)np * 8);
+    else if (gather_blocks) {
+      rc_buf = ensure(c, m->pack, (size_t)per * 8);
+      if (rc_buf == LRN_OK) rc_buf = ensure(c, m->gathered, (size_t)per * m->world * 8);
+    }
+  }
+  const int rc_mine = rc_local != LRN_OK ? rc_local : rc_buf;
+  const std::string err_mine = c->err;
+  double w[3] = {rc_mine == LRN_OK ? 0.0 : 1.0, c->H_partial ? 1.0 : 0.0, c->H_partial ? 0.0 : 1.0};
   int rs = comm_status_max(c, w, 3);
   if (rs != LRN_OK) return rs;
   if (w[0] != 0.0) {
-    if (rc_local != LRN_OK) return rc_local;
+    if (rc_mine != LRN_OK) { c->err = err_mine; return rc_mine; }
     return set_error(c, LRN_ERR_STATE, "Schur assembly failed on another rank");
   }
   if (w[1] != 0.0 && w[2] != 0.0)
     return set_error(c, LRN_ERR_STATE, "ranks disagree on the Schur exchange (partial sums on some, column blocks on others)");
+  c->H_owned_only = false;
+  if (!c->H_partial && !gather_blocks) {      // the CG operator multiplies the columns this rank assembled: nothing to exchange
+    c->H_owned_only = true;
+    return LRN_OK;
+  }
   hipEvent_t a0, a1;
   if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
   if (c->H_partial) {
     // partial sums of the whole matrix: only the lower triangle is authoritative -> n (n + 1) / 2 doubles
-    const long np = (long)n * (n + 1) / 2;
-    LRN_TRY(ensure(c, m->pack, (size_t)np * 8));
     hipLaunchKernelGGL(pack_lower_kernel, dim3(n), dim3(256), 0, c->stream, c->H.as<double>(), n, m->pack.as<double>());
     LRN_TRY(comm_allreduce(c, m->pack.as<double>(), np, 0));
     hipLaunchKernelGGL(unpack_lower_kernel, dim3(n), dim3(256), 0, c->stream, m->pack.as<double>(), n, c->H.as<double>());
     c->H_partial = false;
   } else {
-    const long per = (long)lrn_schur_shard_doubles(c);
-    LRN_TRY(ensure(c, m->pack, (size_t)per * 8));
-    LRN_TRY(ensure(c, m->gathered, (size_t)per * m->world * 8));
     LRN_TRY(lrn_schur_export_shard(c, m->pack.as<double>()));
     LRN_TRY(comm_allgather(c, m->pack.as<double>(), m->gathered.as<double>(), per));
     LRN_TRY(lrn_schur_import_all(c, m->gathered.as<double>()));

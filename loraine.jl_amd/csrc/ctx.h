@@ -104,6 +104,9 @@ struct LrnOptions {
   int lyap_maxit = 300;
   int pair_lanes = 0;             // pair_wave_kernel: lanes per Schur entry, 0 auto (16 for short products), 16, 64
   int matvec_sparse = 0;          // 0 auto, 1 dense GEMM path, 2 sparse path whenever the pattern allows
+  int matvec_h = 0;               // CG operator through the assembled Schur matrix (hop.hip): 0 auto (cost model), 1 never
+                                  // (the matrix-free MyA always), 2 always
+  int pcg_lookahead = 2;          // lrn_pcg: iterations the host queues beyond the one whose convergence test it has read
 };
 
 struct lrn_ctx {
@@ -135,6 +138,19 @@ struct lrn_ctx {
   bool have_H = false, have_L = false;
   bool H_shifted = false;     // lrn_schur_add_diag since the last assembly: strict Cholesky only
   bool H_partial = false;     // world > 1, Cholesky path: H is this rank's partial SUM (exchange = all-reduce)
+  bool H_owned_only = false;  // world > 1: H holds only the column blocks this rank assembled (CG operator, hop.hip)
+  // which NT scaling (W of every block, X_lin ./ S_lin) the assembled H belongs to: scal_version counts the changes of the
+  // scaling, H_version is its value at the last assembly, H_mode the mode of that assembly (0 general, -1 rank-one)
+  long scal_version = 0, H_version = -1;
+  int H_mode = 0;
+  // CG operator through the assembled matrix (hop.hip): the decision taken for scaling `hop_version`, the operator
+  // applications counted under the current and the previous scaling (input of the cost model)
+  long hop_version = -1;
+  bool hop_use = false;
+  long cg_cur_iters = 0, cg_prev_iters = 0;
+  lrn::DBuf hopbuf;           // partial sums of the triangular mat-vec
+  double* pin = nullptr;      // pinned host words: convergence read-back of lrn_pcg
+  hipEvent_t pcg_ev[16] = {};
   // assembly workspaces
   lrn::DBuf P, P2, T, slabs, Hd, BG;
   lrn::DBuf m0, m1, m2, cgbuf;   // msz^2 work matrices (mat-vec / rhs), PCG vectors
@@ -175,9 +191,11 @@ void toc(lrn_ctx* c, const char* key);
 // comm.hip
 int comm_allreduce(lrn_ctx* c, double* buf_dev, long count, int op);     // in place on c->stream; op 0 sum, 1 min, 2 max
 int comm_allgather(lrn_ctx* c, const double* send_dev, double* recv_dev, long count);
-int comm_schur_exchange(lrn_ctx* c, int rc_local);
+int comm_schur_exchange(lrn_ctx* c, int rc_local, bool gather_blocks = true);
 int comm_agree_plan(lrn_ctx* c, int mode);
+int comm_status_max(lrn_ctx* c, double* words, int nw);
 void comm_free(lrn_ctx* c);
+void comm_inject_ensure_failure(lrn_ctx* c);
 // schur.hip
 int schur_assemble(lrn_ctx* c, int mode);
 int schur_plan(lrn_ctx* c, int mode);
@@ -185,7 +203,10 @@ int schur_factor(lrn_ctx* c, int* info);
 int schur_solve(lrn_ctx* c, const double* h, double* dely);
 int schur_add_diag(lrn_ctx* c, double eps);
 int schur_get(lrn_ctx* c, double* Hout);
-int schur_matvec_dense(lrn_ctx* c, const double* x_dev, double* y_dev);
+// hop.hip: the CG operator through the assembled matrix
+int hop_apply(lrn_ctx* c, const double* x_dev, double* y_dev);
+bool hop_worthwhile(lrn_ctx* c, long expected_iters);
+int hop_prepare(lrn_ctx* c);
 }  // namespace lrn
 
 #define LRN_HIP(c, expr)                                                                   \

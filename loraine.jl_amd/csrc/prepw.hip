@@ -214,6 +214,7 @@ int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info) {
   guard.on = false;                                           // (joined through evB above)
   b.have_W = b.have_G = true;
   b.nt_free = false;
+  c->scal_version += 1;
   return LRN_OK;
 }
 
@@ -614,6 +615,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   b.have_W = true;
   b.have_G = false;
   b.nt_free = true;
+  c->scal_version += 1;
   *converged = true;
   return LRN_OK;
 }

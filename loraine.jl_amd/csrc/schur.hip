@@ -959,6 +959,7 @@ int schur_assemble(lrn_ctx* c, int mode) {
   }
   LRN_HIP(c, hipMemsetAsync(c->H.p, 0, (size_t)n * n * 8, c->stream));
   c->H_partial = false;
+  c->H_owned_only = false;
   for (auto& b : c->lmi) {
     if (mode == -1) {
       LRN_TRY(assemble_rank1(c, b));
@@ -991,6 +992,8 @@ int schur_assemble(lrn_ctx* c, int mode) {
   c->have_H = true;
   c->H_shifted = false;
   c->have_L = false;
+  c->H_version = c->scal_version;
+  c->H_mode = mode;
   return LRN_OK;
 }
 
@@ -1016,6 +1019,7 @@ int schur_get(lrn_ctx* c, double* Hout) {
 
 int schur_factor(lrn_ctx* c, int* info) {
   if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  if (c->H_owned_only) return set_error(c, LRN_ERR_STATE, "H holds only this rank's column blocks (call lrn_schur_assemble)");
   const int n = c->nvar;
   size_t bytes = (size_t)n * n * 8;
   LRN_TRY(ensure(c, c->L, bytes));
