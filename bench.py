@@ -426,6 +426,23 @@ def main():
                                for r_ in reports]
             out["exchange_ms_per_step"] = dev.timing("exchange") / args.steps     # status reduction excluded: HIP events around the collective
             out["exchange_transport"] = transport
+        if world == 1 and not os.environ.get("LRN_BENCH_NO_ALONGSIDE"):
+            # prepare_W, the right-hand sides and find_step "reported alongside" -- from a short
+            # device-resident solve of the same instance (first iterations of the real predictor-corrector loop, outside
+            # the timed region): mean over iterations 2.. of the phase times (HIP events on the library's stream)
+            from loraine_jl_amd.synthetic import synthetic_dense_solver
+            solver, ha = synthetic_dense_solver(dev, msz, nvar, seed=args.seed, options=dict(kit=0, verb=0, maxit=4))
+            solver.solve(ha)
+            tr = solver.trace[1:] if len(solver.trace) > 1 else solver.trace
+            mean = lambda f: float(np.mean([f(x) for x in tr])) if tr else None
+            out["alongside"] = {
+                "source": "resident IP solve of the same instance, iterations 2..%d (outside the timed region)" % len(solver.trace),
+                "prepare_w_ms": mean(lambda x: x["gpu_ms"]["prepare_w"]),
+                "rhs_ms": mean(lambda x: x["rhs_ms"]), "residual_d_ms": mean(lambda x: x["residual_d_ms"]),
+                "find_step_ms": mean(lambda x: x["find_step_ms"]), "lyapunov_ms": mean(lambda x: x["lyap_ms"]),
+                "assemble_ms": mean(lambda x: x["gpu_ms"]["assemble"]), "factor_ms": mean(lambda x: x["gpu_ms"]["factor"]),
+                "solve_ms": mean(lambda x: x["gpu_ms"]["solve"]),
+                "full_iteration_ms": mean(lambda x: x["itertime"] * 1e3)}
         if world == 1 and not args.no_cpu_baseline:
             dev.close()
             out["cpu_baseline"] = cpu_baseline(args.cpu_msz, args.cpu_nvar, args.seed + 7, args.cpu_msz2,

@@ -61,6 +61,8 @@ int lrn_destroy(lrn_ctx* c) {
   release(c->commvec);
   release(c->commmat);
   release(c->hopbuf);
+  release(c->triw);
+  release(c->cgpart);
   if (c->pin) (void)hipHostFree(c->pin);
   for (hipEvent_t e : c->pcg_ev) if (e) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
@@ -115,6 +117,8 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "nt_mode")) c->opt.nt_mode = (int)value;
   else if (!strcmp(key, "prec_inv")) c->opt.prec_inv = (int)value;
   else if (!strcmp(key, "shard_passes")) c->opt.shard_passes = (int)value;
+  else if (!strcmp(key, "shard_products")) c->opt.shard_products = (int)value;
+  else if (!strcmp(key, "shard_products_min")) c->opt.shard_products_min = std::max(16, (int)value);
   else if (!strcmp(key, "ns_l0")) c->opt.ns_l0 = value;
   else if (!strcmp(key, "ns_maxit")) c->opt.ns_maxit = (int)value;
   else if (!strcmp(key, "ns_dual")) c->opt.ns_dual = (int)value;

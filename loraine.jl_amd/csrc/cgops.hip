@@ -292,6 +292,151 @@ __global__ __launch_bounds__(256) void aat_dense2_kernel(const double* __restric
   *m2 -= s0 + s1;
 }
 
+// ---- round 4: the same passes over HALF the bytes.  Every A_k is symmetric, so <A_k, Z> = sum_{i>=j} A_k[i,j] w[i,j] with
+// w = Z + Z' below the diagonal, Z on it, and mat(AA'x) is the mirror image of its lower triangle.  Only the column tails
+// rows >= j of each matrix are streamed (they are contiguous in the column-major storage), cut into chunks of 64 x 16 bytes
+// = 128 rows listed in a table built once per matrix side (TriChunk; the tails start at j rounded down to 16 rows so that
+// every chunk is 128-byte aligned: 0.8 % of over-read at msz 2000, covered by zero weights / masked stores).  One wave per
+// chunk; the workgroup's four chunks are consecutive in the table, i.e. mostly one contiguous 4 KB piece of a column.
+struct TriChunk { long off; int col; int nv2; };      // first element (doubles), column, valid 16-byte pairs (<= 64)
+
+// w = tri-weights of Z: Z + Z' strictly below the diagonal, Z on it, zero above
+__global__ void tri_weights_kernel(const double* __restrict__ Z, int n, double* __restrict__ Wt) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;      // output tile rows bx.., columns by..
+  if (bx + 31 < by) {                                          // entirely above the diagonal
+    for (int r = threadIdx.y; r < 32; r += 8) {
+      const int i = bx + threadIdx.x, j = by + r;
+      if (i < n && j < n) Wt[(long)i + (long)j * n] = 0.0;
+    }
+    return;
+  }
+  for (int r = threadIdx.y; r < 32; r += 8) {                  // tile[r][t] = Z[by + t, bx + r]  (the transposed block)
+    const int i = by + threadIdx.x, j = bx + r;
+    if (i < n && j < n) tile[r][threadIdx.x] = Z[(long)i + (long)j * n];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int i = bx + threadIdx.x, j = by + r;
+    if (i < n && j < n) {
+      const double a = Z[(long)i + (long)j * n];
+      Wt[(long)i + (long)j * n] = i > j ? a + tile[threadIdx.x][r] : (i == j ? a : 0.0);
+    }
+  }
+}
+
+// upper triangle <- lower triangle
+__global__ void mirror_lower_tiled_kernel(double* __restrict__ A, int n) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;      // source tile rows bx.., columns by.. (on or below the diagonal)
+  if (bx < by) return;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int i = bx + threadIdx.x, j = by + r;
+    if (i < n && j < n) tile[r][threadIdx.x] = A[(long)i + (long)j * n];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int i = by + threadIdx.x, j = bx + r;              // destination (i, j) = transposed position
+    if (i < n && j < n && i < j) A[(long)i + (long)j * n] = tile[threadIdx.x][r];
+  }
+}
+
+// out[sigma[p]] -= <A_p, Z> for NZ weight matrices at once (NZ = 1, 2), four constraints per workgroup
+template <int NZ>
+__global__ __launch_bounds__(256) void aa_dense_tri_dot4_kernel(const double* __restrict__ Ad, long mm, int nd,
+                                                                const double* __restrict__ W1, const double* __restrict__ W2,
+                                                                const TriChunk* __restrict__ tab, int nch,
+                                                                const int* __restrict__ sigma, double* __restrict__ out1,
+                                                                double* __restrict__ out2) {
+  __shared__ double sh[4 * NZ][4];
+  const int p0 = blockIdx.x * 4;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const v2f64* a2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a2[k] = reinterpret_cast<const v2f64*>(Ad + (long)(p0 + k < nd ? p0 + k : p0) * mm);
+  const v2f64* w1 = reinterpret_cast<const v2f64*>(W1);
+  const v2f64* w2 = reinterpret_cast<const v2f64*>(NZ > 1 ? W2 : W1);
+  double s[4 * NZ];
+#pragma unroll
+  for (int k = 0; k < 4 * NZ; ++k) s[k] = 0.0;
+  for (int ch = w; ch < nch; ch += 8) {
+    const TriChunk e0 = tab[ch];
+    const bool two = ch + 4 < nch;
+    const TriChunk e1 = tab[two ? ch + 4 : ch];
+    const bool v0 = lane < e0.nv2, v1 = two && lane < e1.nv2;
+    const long q0 = (e0.off >> 1) + (v0 ? lane : 0), q1 = (e1.off >> 1) + (v1 ? lane : 0);
+    v2f64 a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a0[k] = __builtin_nontemporal_load(a2[k] + q0); a1[k] = __builtin_nontemporal_load(a2[k] + q1); }
+    v2f64 y0 = w1[q0], y1 = w1[q1];
+    if (!v0) y0 = (v2f64){0.0, 0.0};
+    if (!v1) y1 = (v2f64){0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] += (a0[k].x * y0.x + a0[k].y * y0.y) + (a1[k].x * y1.x + a1[k].y * y1.y);
+    if (NZ > 1) {
+      v2f64 z0 = w2[q0], z1 = w2[q1];
+      if (!v0) z0 = (v2f64){0.0, 0.0};
+      if (!v1) z1 = (v2f64){0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[4 + k] += (a0[k].x * z0.x + a0[k].y * z0.y) + (a1[k].x * z1.x + a1[k].y * z1.y);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4 * NZ; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+    if (lane == 0) sh[k][w] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * NZ && p0 + (int)(threadIdx.x & 3) < nd) {
+    const int k = threadIdx.x;
+    const double v = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+    if (k < 4) out1[sigma[p0 + k]] -= v;
+    else out2[sigma[p0 + k - 4]] -= v;
+  }
+}
+
+// lower triangle of M -= sum_p x[sigma[p]] A_p: one wave per chunk, eight matrices in flight per lane
+__global__ __launch_bounds__(256) void aat_dense_tri_kernel(const double* __restrict__ Ad, int nd, long mm, int m,
+                                                            const int* __restrict__ sigma, const double* __restrict__ x,
+                                                            const TriChunk* __restrict__ tab, int nch, double* __restrict__ M) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (ch >= nch) return;
+  const TriChunk e = tab[ch];
+  if (lane >= e.nv2) return;
+  const long n2 = mm >> 1;
+  const v2f64* a2 = reinterpret_cast<const v2f64*>(Ad) + (e.off >> 1) + lane;
+  v2f64 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
+  int p = 0;
+  for (; p + 8 <= nd; p += 8) {
+    v2f64 a[8];
+    double xs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = __builtin_nontemporal_load(a2 + (long)(p + k) * n2); xs[k] = x[sigma[p + k]]; }
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) { s0 += xs[k] * a[k]; s1 += xs[k + 1] * a[k + 1]; }
+  }
+  for (; p < nd; ++p) s0 += x[sigma[p]] * a2[(long)p * n2];
+  const v2f64 t = s0 + s1;
+  double* mp = M + e.off + 2 * lane;
+  const int r = (int)(e.off - (long)e.col * m) + 2 * lane;      // row of the first element of the pair
+  if (r >= e.col) mp[0] -= t.x;
+  if (r + 1 >= e.col) mp[1] -= t.y;
+}
+
+// is every dense constraint matrix symmetric?  flag[0] = 1 when a pair differs
+__global__ __launch_bounds__(256) void dense_sym_check_kernel(const double* __restrict__ Ad, int m, int* __restrict__ flag) {
+  const double* A = Ad + (long)blockIdx.x * m * m;
+  bool bad = false;
+  for (long e = threadIdx.x; e < (long)m * m; e += 256) {
+    const int i = (int)(e % m), j = (int)(e / m);
+    if (i > j && A[e] != A[(long)j + (long)i * m]) bad = true;
+  }
+  if (bad) flag[0] = 1;
+}
+
 // row-sharded variants (multi-GPU mat-vec): only entries with r0 <= row < r1; Zg holds the rows
 // [r0,r1) of Z with leading dimension ldz
 __global__ __launch_bounds__(256) void aa_times_rows_kernel(const long* __restrict__ ptr, const int* __restrict__ er,
@@ -622,6 +767,48 @@ __global__ __launch_bounds__(256) void sp_aa_times_kernel(const long* __restrict
   if (lane == 0) out[sigma[p]] -= s;
 }
 
+// The half-traffic passes (column tails of the symmetric matrices): table of chunks, built once per block
+static int tri_table(lrn_ctx* c, LmiBlock& b) {
+  if (b.tri_nch > 0) return LRN_OK;
+  const int m = b.msz;
+  std::vector<TriChunk> tab;
+  for (int j = 0; j < m; ++j) {
+    const int r0 = j & ~15;
+    for (int r = r0; r < m; r += 128) tab.push_back({(long)j * m + r, j, std::min(64, (m - r) / 2)});
+  }
+  LRN_TRY(ensure(c, b.tri_tab, tab.size() * sizeof(TriChunk)));
+  LRN_TRY(copy_in(c, b.tri_tab.p, tab.data(), tab.size() * sizeof(TriChunk)));
+  b.tri_nch = (int)tab.size();
+  return LRN_OK;
+}
+
+// symmetric dense data (checked once on the device), msz even (16-byte pairs), enough data to be a stream
+static bool dense_tri_ok(lrn_ctx* c, LmiBlock& b) {
+  static const bool off = getenv("LRN_DENSE_PASS_FULL") != nullptr;       // (measurement: the round-3 kernels, both triangles)
+  if (off || b.nd <= 0 || (b.msz & 1) != 0 || b.msz < 256 || ((uintptr_t)b.Adense.p & 15) != 0) return false;
+  if (b.dense_sym < 0) {
+    if (ensure(c, c->info_dev, 64) != LRN_OK) return false;
+    (void)hipMemsetAsync(c->info_dev.p, 0, 4, c->stream);
+    hipLaunchKernelGGL(dense_sym_check_kernel, dim3(b.nd), dim3(256), 0, c->stream, b.Adense.as<double>(), b.msz,
+                       c->info_dev.as<int>());
+    int f = 1;
+    if (copy_out(c, &f, c->info_dev.p, 4) != LRN_OK) return false;
+    (void)hipMemsetAsync(c->info_dev.p, 0, 4, c->stream);
+    b.dense_sym = f == 0 ? 1 : 0;
+  }
+  return b.dense_sym == 1 && tri_table(c, b) == LRN_OK;
+}
+
+// w = tri-weights of Z into slot `which` of the block's weight workspace
+static int tri_weights(lrn_ctx* c, LmiBlock& b, const double* Z, int which, double** out) {
+  const int m = b.msz;
+  LRN_TRY(ensure(c, c->triw, (size_t)2 * m * m * 8));
+  double* Wt = c->triw.as<double>() + (size_t)which * m * m;
+  hipLaunchKernelGGL(tri_weights_kernel, dim3((m + 31) / 32, (m + 31) / 32), dim3(32, 8), 0, c->stream, Z, m, Wt);
+  *out = Wt;
+  return LRN_OK;
+}
+
 // the 16-byte kernels of the dense passes: every matrix 16-byte aligned (msz even), enough data to be a stream
 static bool dense_stream_ok(const LmiBlock& b, const double* Z) {
   static const bool off = getenv("LRN_DENSE_PASS_SCALAR") != nullptr;      // (measurement: the one-element-per-lane kernels)
@@ -699,6 +886,10 @@ static bool dense_passes_sharded(lrn_ctx* c, const LmiBlock& b) {
 
 int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
   const int m = b.msz;
+  if (products_sharded(c, c->stream, m)) {      // P = W M' (M symmetric), Z = P W' (W symmetric): column blocks + all-gather
+    LRN_TRY(pgemm_nt(c, c->stream, m, b.W.as<double>(), M, P));
+    return pgemm_nt(c, c->stream, m, P, b.W.as<double>(), Z);
+  }
   GemmDesc g1;     // P = W M   (M symmetric: read as M[n + k*m] -> direct-to-LDS path)
   g1.A = b.W.as<double>(); g1.sAm = 1; g1.sAk = m;
   g1.B = M; g1.sBk = m; g1.sBn = 1;
@@ -739,7 +930,14 @@ int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
       LRN_TRY(ensure(c, c->commvec, (size_t)c->nvar * 8));
       LRN_HIP(c, hipMemsetAsync(c->commvec.p, 0, (size_t)c->nvar * 8, c->stream));
       if (p1 > p0) {
-        if (dense_stream_ok(b, Z))
+        if (dense_tri_ok(c, b)) {
+          double* Wt = nullptr;
+          LRN_TRY(tri_weights(c, b, Z, 0, &Wt));
+          hipLaunchKernelGGL(aa_dense_tri_dot4_kernel<1>, dim3((p1 - p0 + 3) / 4), dim3(256), 0, c->stream,
+                             b.Adense.as<double>() + (long)p0 * b.msz * b.msz, (long)b.msz * b.msz, p1 - p0, Wt, Wt,
+                             b.tri_tab.as<TriChunk>(), b.tri_nch, b.sigma_d.as<int>() + p0, c->commvec.as<double>(),
+                             c->commvec.as<double>());
+        } else if (dense_stream_ok(b, Z))
           hipLaunchKernelGGL(aa_dense_dot4_kernel, dim3((p1 - p0 + 3) / 4), dim3(256), 0, c->stream,
                              b.Adense.as<double>() + (long)p0 * b.msz * b.msz, (long)b.msz * b.msz, p1 - p0, Z,
                              b.sigma_d.as<int>() + p0, c->commvec.as<double>());
@@ -752,7 +950,12 @@ int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y) {
       hipLaunchKernelGGL(vec_add_kernel, dim3(nb(c->nvar)), dim3(256), 0, c->stream, y, c->commvec.as<double>(), c->nvar);
       return LRN_OK;
     }
-    if (dense_stream_ok(b, Z))
+    if (dense_tri_ok(c, b)) {
+      double* Wt = nullptr;
+      LRN_TRY(tri_weights(c, b, Z, 0, &Wt));
+      hipLaunchKernelGGL(aa_dense_tri_dot4_kernel<1>, dim3((b.nd + 3) / 4), dim3(256), 0, c->stream, b.Adense.as<double>(),
+                         (long)b.msz * b.msz, b.nd, Wt, Wt, b.tri_tab.as<TriChunk>(), b.tri_nch, b.sigma_d.as<int>(), y, y);
+    } else if (dense_stream_ok(b, Z))
       hipLaunchKernelGGL(aa_dense_dot4_kernel, dim3((b.nd + 3) / 4), dim3(256), 0, c->stream, b.Adense.as<double>(),
                          (long)b.msz * b.msz, b.nd, Z, b.sigma_d.as<int>(), y);
     else
@@ -793,7 +996,13 @@ int aa_times2(lrn_ctx* c, LmiBlock& b, const double* Z1, double* y1, const doubl
                          b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(), h ? Z2 : Z1, b.msz, b.nd, b.npos_nz,
                          b.sigma_d.as<int>(), h ? y2 : y1);
   }
-  if (dense_stream_ok(b, Z1) && dense_stream_ok(b, Z2))
+  if (dense_tri_ok(c, b)) {
+    double *W1 = nullptr, *W2 = nullptr;
+    LRN_TRY(tri_weights(c, b, Z1, 0, &W1));
+    LRN_TRY(tri_weights(c, b, Z2, 1, &W2));
+    hipLaunchKernelGGL(aa_dense_tri_dot4_kernel<2>, dim3((b.nd + 3) / 4), dim3(256), 0, c->stream, b.Adense.as<double>(),
+                       (long)b.msz * b.msz, b.nd, W1, W2, b.tri_tab.as<TriChunk>(), b.tri_nch, b.sigma_d.as<int>(), y1, y2);
+  } else if (dense_stream_ok(b, Z1) && dense_stream_ok(b, Z2))
     hipLaunchKernelGGL(aa_dense_dot4x2_kernel, dim3((b.nd + 3) / 4), dim3(256), 0, c->stream, b.Adense.as<double>(),
                        (long)b.msz * b.msz, b.nd, Z1, Z2, b.sigma_d.as<int>(), y1, y2);
   else
@@ -810,34 +1019,44 @@ int aat_to_mat(lrn_ctx* c, LmiBlock& b, const double* x, double* M) {
   if (b.ncq > 0)
     hipLaunchKernelGGL(aat_gather_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, c->stream, b.cq_q.as<long>(),
                        b.cq_ptr.as<long>(), b.cq_j.as<int>(), b.cq_v.as<double>(), b.ncq, x, M);
+  // symmetric dense data: the sparse part is symmetrised first, the dense constraints are added to the LOWER triangle only
+  // (half the bytes of the pass) and the result is mirrored -- the same matrix up to the order of the additions
+  const bool tri = b.nd > 0 && dense_tri_ok(c, b);
+  if (tri && b.ncq > 0) hipLaunchKernelGGL(symmetrize_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, m);
   if (b.nd > 0) {
-    if (dense_passes_sharded(c, b)) {
+    int p0 = 0, p1 = b.nd;
+    double* Tm = M;
+    const bool sharded = dense_passes_sharded(c, b);
+    if (sharded) {
       // this rank's constraints into a zeroed buffer, one all-reduce of the msz x msz partial sums, then added to M
       const int per = (b.nd + c->world - 1) / c->world;
-      const int p0 = std::min(b.nd, c->rank * per), p1 = std::min(b.nd, p0 + per);
+      p0 = std::min(b.nd, c->rank * per);
+      p1 = std::min(b.nd, p0 + per);
       LRN_TRY(ensure(c, c->commmat, (size_t)mm * 8));
-      double* Tm = c->commmat.as<double>();
+      Tm = c->commmat.as<double>();
       LRN_HIP(c, hipMemsetAsync(Tm, 0, (size_t)mm * 8, c->stream));
-      if (p1 > p0) {
-        if (dense_stream_ok(b, Tm))
-          hipLaunchKernelGGL(aat_dense2_kernel, dim3((unsigned)((mm / 2 + 255) / 256)), dim3(256), 0, c->stream,
-                             b.Adense.as<double>() + (long)p0 * mm, p1 - p0, mm, b.sigma_d.as<int>() + p0, x, Tm);
-        else
-        hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>() + (long)p0 * mm,
-                           p1 - p0, mm, b.sigma_d.as<int>() + p0, x, Tm);
-      }
+    }
+    if (p1 > p0) {
+      const double* Ap0 = b.Adense.as<double>() + (long)p0 * mm;
+      const int* sg = b.sigma_d.as<int>() + p0;
+      if (tri)
+        hipLaunchKernelGGL(aat_dense_tri_kernel, dim3((unsigned)((b.tri_nch + 3) / 4)), dim3(256), 0, c->stream, Ap0, p1 - p0,
+                           mm, m, sg, x, b.tri_tab.as<TriChunk>(), b.tri_nch, Tm);
+      else if (dense_stream_ok(b, Tm))
+        hipLaunchKernelGGL(aat_dense2_kernel, dim3((unsigned)((mm / 2 + 255) / 256)), dim3(256), 0, c->stream, Ap0, p1 - p0, mm,
+                           sg, x, Tm);
+      else
+        hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, Ap0, p1 - p0, mm, sg, x, Tm);
+    }
+    if (sharded) {
       LRN_TRY(comm_allreduce(c, Tm, mm, 0));
       hipLaunchKernelGGL(vec_add_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, Tm, mm);
-    } else {
-      if (dense_stream_ok(b, M))
-        hipLaunchKernelGGL(aat_dense2_kernel, dim3((unsigned)((mm / 2 + 255) / 256)), dim3(256), 0, c->stream,
-                           b.Adense.as<double>(), b.nd, mm, b.sigma_d.as<int>(), x, M);
-      else
-      hipLaunchKernelGGL(aat_dense_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, b.Adense.as<double>(), b.nd, mm,
-                         b.sigma_d.as<int>(), x, M);
     }
   }
-  hipLaunchKernelGGL(symmetrize_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, m);
+  if (tri)
+    hipLaunchKernelGGL(mirror_lower_tiled_kernel, dim3((m + 31) / 32, (m + 31) / 32), dim3(32, 8), 0, c->stream, M, m);
+  else
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nb(mm)), dim3(256), 0, c->stream, M, m);
   return LRN_OK;
 }
 
@@ -928,48 +1147,105 @@ __global__ __launch_bounds__(1024) void cg_norm_kernel(const double* __restrict_
   if (threadIdx.x == 0) scal[slot] = s;
 }
 
-// scal[8] = exit code once the iteration has ended (30 converged, -13 alpha invalid), scal[9] = the iteration it ended
-// in: the host queues iterations ahead of the convergence test it has read (option pcg_lookahead); the kernels of the
-// iterations queued beyond the last one find the flag set and leave x, r, p alone -- the iteration count and the
-// result are those of the loop that tests after every step (ConjugateGradients.jl)
-__global__ __launch_bounds__(1024) void cg_alpha_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
-                                                        const double* __restrict__ z, double* __restrict__ r,
-                                                        double* __restrict__ x, int n, double* __restrict__ scal, int it,
-                                                        double res0, double tol) {
-  __shared__ double sh[16];
-  if (scal[8] != 0.0) return;
-  double g = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) { g += r[i] * z[i]; q += p[i] * Ap[i]; }
-  g = wg_sum1024(g, sh);
-  q = wg_sum1024(q, sh);
-  double alpha = g / q;
-  bool bad = !(alpha >= 0.0) || isinf(alpha);
-  double rr = 0.0;
-  if (!bad)
-    for (int i = threadIdx.x; i < n; i += 1024) {
-      x[i] += alpha * p[i];
-      double ri = r[i] - alpha * Ap[i];
-      r[i] = ri;
-      rr += ri * ri;
-    }
-  rr = wg_sum1024(rr, sh);
-  if (threadIdx.x == 0) {
-    scal[0] = g; scal[1] = q; scal[2] = alpha; scal[3] = rr; scal[4] = bad ? 1.0 : 0.0;
-    if (bad) { scal[8] = -13.0; scal[9] = (double)it; }
-    else if (sqrt(rr) / res0 <= tol) { scal[8] = 30.0; scal[9] = (double)it; }
-  }
+// ---- the CG recurrence as two multi-workgroup launches per iteration (round 4; round 3: two single-workgroup kernels of
+// 33 + 15 us at nvar 20 000 and a host read between them).
+//   cg_b_kernel(it): q = p'Ap (from the partial sums the operator left, or a redundant dot per workgroup), alpha = g / q,
+//                    x += alpha p, r -= alpha Ap on the workgroup's slice, z = M^-1 r inline when the preconditioner is
+//                    diagonal (none, H_beta), partial sums of r'r and z'r
+//   cg_d_kernel(it): r'r -> the convergence test of ConjugateGradients.jl (relative residual <= tol); z'r, beta,
+//                    p = z + beta p on the slice
+// Every workgroup forms the global scalars itself from the same partials in the same order: no grid barrier, no atomics,
+// all workgroups take the same branch.  scal[8] = exit code once the iteration has ended (30 converged, -13 alpha
+// invalid), scal[9] = the iteration it ended in, both mirrored to host-mapped words: the host queues iterations ahead of
+// the test it has read (option pcg_lookahead); kernels queued beyond the last iteration find the flag set and leave
+// x, r, p alone -- count and result are those of the loop that tests after every step.  g = r'z alternates between
+// scal[10] and scal[11] (a workgroup of cg_d_kernel must not overwrite the value its neighbours are still reading).
+__device__ __forceinline__ double wg_sum256(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(1024) void cg_beta_kernel(const double* __restrict__ z, const double* __restrict__ r,
-                                                       double* __restrict__ p, int n, double* __restrict__ scal) {
-  __shared__ double sh[16];
+static constexpr int CG_MAXWG = 256;
+
+__global__ __launch_bounds__(256) void cg_b_kernel(const double* __restrict__ p, const double* __restrict__ Ap,
+                                                   double* __restrict__ r, double* __restrict__ x, double* __restrict__ z,
+                                                   int kind, const double* __restrict__ d, int n, int per,
+                                                   double* __restrict__ scal, const double* __restrict__ qpart, int nq,
+                                                   double* __restrict__ rrpart, double* __restrict__ zrpart,
+                                                   double* __restrict__ hostw, int it) {
+  __shared__ double sh[4];
   if (scal[8] != 0.0) return;
+  double q = 0.0;
+  if (qpart) for (int i = threadIdx.x; i < nq; i += 256) q += qpart[i];
+  else for (int i = threadIdx.x; i < n; i += 256) q += p[i] * Ap[i];
+  q = wg_sum256(q, sh);
+  const double g = scal[10 + ((it - 1) & 1)];
+  const double alpha = g / q;
+  const bool bad = !(alpha >= 0.0) || isinf(alpha);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal[1] = q; scal[2] = alpha; scal[4] = bad ? 1.0 : 0.0; }
+  if (bad) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      scal[9] = (double)it;
+      hostw[1] = (double)it;
+      hostw[0] = -13.0;
+      __threadfence_system();
+      scal[8] = -13.0;
+    }
+    return;
+  }
+  const int i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+  double rr = 0.0, zr = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * Ap[i];
+    r[i] = ri;
+    rr += ri * ri;
+    if (kind == 0) { z[i] = ri; zr += ri * ri; }                       // MyM_no   (Solvers.jl:620-622)
+    else if (kind == 2) { const double zi = ri / d[i]; z[i] = zi; zr += zi * ri; }   // MyM_beta (:670-672)
+  }
+  rr = wg_sum256(rr, sh);
+  zr = wg_sum256(zr, sh);
+  if (threadIdx.x == 0) { rrpart[blockIdx.x] = rr; zrpart[blockIdx.x] = zr; }
+}
+
+// first != 0: the start of the iteration, p = z, g = z'r (no test, no beta)
+__global__ __launch_bounds__(256) void cg_d_kernel(const double* __restrict__ z, const double* __restrict__ r,
+                                                   double* __restrict__ p, int n, int per, int nwg,
+                                                   double* __restrict__ scal, const double* __restrict__ rrpart,
+                                                   const double* __restrict__ zrpart, double* __restrict__ hostw, int it,
+                                                   double res0, double tol, int first) {
+  __shared__ double sh[4];
+  if (scal[8] != 0.0) return;
+  if (!first) {
+    double rr = 0.0;
+    for (int i = threadIdx.x; i < nwg; i += 256) rr += rrpart[i];
+    rr = wg_sum256(rr, sh);
+    if (sqrt(rr) / res0 <= tol) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal[3] = rr;
+        scal[9] = (double)it;
+        hostw[1] = (double)it;
+        hostw[0] = 30.0;
+        __threadfence_system();
+        scal[8] = 30.0;
+      }
+      return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[3] = rr;
+  }
   double zr = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) zr += z[i] * r[i];
-  zr = wg_sum1024(zr, sh);
-  double beta = zr / scal[0];
-  for (int i = threadIdx.x; i < n; i += 1024) p[i] = z[i] + beta * p[i];
-  if (threadIdx.x == 0) { scal[5] = beta; scal[7] = zr; }
+  if (zrpart) for (int i = threadIdx.x; i < nwg; i += 256) zr += zrpart[i];
+  else for (int i = threadIdx.x; i < n; i += 256) zr += z[i] * r[i];
+  zr = wg_sum256(zr, sh);
+  const double beta = first ? 0.0 : zr / scal[10 + ((it - 1) & 1)];
+  const int i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+  if (first) for (int i = i0 + threadIdx.x; i < i1; i += 256) p[i] = z[i];
+  else for (int i = i0 + threadIdx.x; i < i1; i += 256) p[i] = z[i] + beta * p[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scal[10 + (it & 1)] = zr; scal[5] = beta; scal[7] = zr; }
 }
 
 __global__ void div_kernel(const double* __restrict__ x, const double* __restrict__ d, double* __restrict__ y, int n, int sq) {
@@ -982,12 +1258,14 @@ __global__ void fill_kernel(double* __restrict__ d, int n, double v) {
   if (i < n) d[i] = v;
 }
 
-// y[c] = sum_i ts[i + c*n] v[i]   (one workgroup per column)
+// y[c] = sum_i ts[i + c*n] v[i]   (one workgroup per column); d != null: v[i] = x[i] / sqrt(d[i]) formed on the fly
 __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ ts, int n, const double* __restrict__ v,
-                                                     double* __restrict__ y) {
+                                                     const double* __restrict__ d, double* __restrict__ y) {
   __shared__ double sh[4];
   const double* col = ts + (long)blockIdx.x * n;
   double s = 0.0;
+  if (d) for (int i = threadIdx.x; i < n; i += 256) s += col[i] * (v[i] / sqrt(d[i]));
+  else
   for (int i = threadIdx.x; i < n; i += 256) s += col[i] * v[i];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -1007,14 +1285,15 @@ __global__ __launch_bounds__(256) void gemv_n_part_kernel(const double* __restri
   zpart[(long)blockIdx.y * n + i] = s;
 }
 
-// out = (v - sum_chunks zpart) / sqrt(d)
+// out = (v - sum_chunks zpart) / sqrt(d); scaled != 0: v = x / sqrt(d) formed on the fly from x
 __global__ void smw_final_kernel(const double* __restrict__ v, const double* __restrict__ zpart, int nchunk, int n,
-                                 const double* __restrict__ d, double* __restrict__ out) {
+                                 const double* __restrict__ d, double* __restrict__ out, int scaled) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double s = 0.0;
   for (int k = 0; k < nchunk; ++k) s += zpart[(long)k * n + i];
-  out[i] = (v[i] - s) / sqrt(d[i]);
+  const double sd = sqrt(d[i]);
+  out[i] = ((scaled ? v[i] / sd : v[i]) - s) / sd;
 }
 
 // ------------------------------------------------------------------ H_alpha setup kernels
@@ -1350,11 +1629,16 @@ int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
     return LRN_OK;
   }
   const int ksz = P->ksz;                                    // MyM (Solvers.jl:866-904), ts form
-  hipLaunchKernelGGL(div_kernel, dim3(nb(n)), dim3(256), 0, st, x, P->d.as<double>(), tmpv, n, 1);
-  if (P->has_LD)        // v = L_D^-1 x  (d holds ones)
+  if (P->has_LD) {      // v = L_D^-1 x  (d holds ones)
+    hipLaunchKernelGGL(div_kernel, dim3(nb(n)), dim3(256), 0, st, x, P->d.as<double>(), tmpv, n, 1);
     LRN_TRY(trsm_left_lower(st, P->LD.as<double>(), n, n, P->linvD.as<double>(), false, tmpv, 1, n,
                             P->wD.as<double>() + (size_t)n * CHOL_NB));
-  hipLaunchKernelGGL(gemv_t_kernel, dim3(ksz), dim3(256), 0, st, P->ts.as<double>(), n, tmpv, P->y.as<double>());
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(ksz), dim3(256), 0, st, P->ts.as<double>(), n, tmpv, (const double*)nullptr,
+                       P->y.as<double>());
+  } else {              // v = x ./ sqrt(d) formed inside the two kernels that read it (same operations, one launch less)
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(ksz), dim3(256), 0, st, P->ts.as<double>(), n, x, P->d.as<double>(),
+                       P->y.as<double>());
+  }
   if (P->has_inv) {
     // y2 = Ainv y; refinement: y3 = y - (S + I) y2, y2 += Ainv y3 -- the accuracy of the triangular solves, three launches
     const unsigned g16 = (unsigned)((ksz + 15) / 16);
@@ -1373,8 +1657,8 @@ int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
   const int cper = (ksz + nchunk - 1) / nchunk;
   hipLaunchKernelGGL(gemv_n_part_kernel, dim3((n + 255) / 256, nchunk), dim3(256), 0, st, P->ts.as<double>(), n, ksz,
                      cper, P->y2.as<double>(), P->zpart.as<double>());
-  hipLaunchKernelGGL(smw_final_kernel, dim3(nb(n)), dim3(256), 0, st, tmpv, P->zpart.as<double>(), nchunk, n,
-                     P->d.as<double>(), Mx);
+  hipLaunchKernelGGL(smw_final_kernel, dim3(nb(n)), dim3(256), 0, st, P->has_LD ? tmpv : x, P->zpart.as<double>(), nchunk, n,
+                     P->d.as<double>(), Mx, P->has_LD ? 0 : 1);
   if (P->has_LD)
     LRN_TRY(trsm_left_lower(st, P->LD.as<double>(), n, n, P->linvD.as<double>(), true, Mx, 1, n,
                             P->wD.as<double>() + (size_t)n * CHOL_NB));
@@ -1411,10 +1695,11 @@ int op_select(lrn_ctx* c, bool* use_h) {
 }
 
 // Ap = A p by the selected operator (all-reduced when sharded)
-static int op_apply(lrn_ctx* c, bool use_h, const double* p, double* Ap) {
+static int op_apply(lrn_ctx* c, bool use_h, const double* p, double* Ap, double* qpart = nullptr, int* nq = nullptr) {
   const bool sharded = c->comm && c->world > 1;
+  if (nq) *nq = 0;
   if (use_h) {
-    LRN_TRY(hop_apply(c, p, Ap));
+    LRN_TRY(hop_apply(c, p, Ap, qpart, nq));
   } else if (sharded) {
     // one process per GPU: this rank's rows of W M W, then ONE all-reduce of the nvar-vector on this stream -- the
     // recurrence is replicated and stays on the device, as on one GPU
@@ -1438,51 +1723,68 @@ int pcg_dev(lrn_ctx* c, const double* b, double tol, int maxit, double* x, int* 
   double* tmpv = Ap + n;
   double* scal = tmpv + n;          // 16 doubles
   constexpr int NSLOT = 16;
-  if (!c->pin) LRN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin), NSLOT * 16 * 8, hipHostMallocDefault));
+  if (!c->pin) {
+    LRN_HIP(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin), NSLOT * 16 * 8, hipHostMallocMapped));
+    LRN_HIP(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->pin_dev), c->pin, 0));
+  }
   if (!c->pcg_ev[0])
     for (int i = 0; i < NSLOT; ++i) LRN_HIP(c, hipEventCreateWithFlags(&c->pcg_ev[i], hipEventDisableTiming));
-  double* hs = c->pin;
+  volatile double* hs = c->pin;
+  // partial sums of the recurrence kernels and of the operator (hop.hip): after the six vectors
+  const int nwg = std::max(1, std::min(CG_MAXWG, (n + 255) / 256));
+  const int per = (n + nwg - 1) / nwg;
+  LRN_TRY(ensure(c, c->cgpart, (size_t)(2 * CG_MAXWG + (n + 63) / 64 + 64) * 8));
+  double* rrpart = c->cgpart.as<double>();
+  double* zrpart = rrpart + CG_MAXWG;
+  double* qpart = zrpart + CG_MAXWG;
   long nmv = 0;
   LRN_HIP(c, hipMemsetAsync(x, 0, (size_t)n * 8, st));
   LRN_HIP(c, hipMemsetAsync(scal, 0, 16 * 8, st));
   hipLaunchKernelGGL(cg_norm_kernel, dim3(1), dim3(1024), 0, st, b, n, scal, 6);
-  LRN_HIP(c, hipMemcpyAsync(hs, scal + 6, 8, hipMemcpyDeviceToHost, st));
+  double bb = 0.0;
+  LRN_HIP(c, hipMemcpyAsync(&bb, scal + 6, 8, hipMemcpyDeviceToHost, st));
   LRN_HIP(c, hipStreamSynchronize(st));
-  if (std::sqrt(hs[0]) == 0.0) { *exit_code = 1; *iters = 0; return LRN_OK; }
+  if (std::sqrt(bb) == 0.0) { *exit_code = 1; *iters = 0; return LRN_OK; }
   // r = b - A*0 = b
   LRN_HIP(c, hipMemcpyAsync(r, b, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-  const double residual_0 = std::sqrt(hs[0]);
+  const double residual_0 = std::sqrt(bb);
   if (residual_0 <= tol) { *exit_code = 2; *iters = 0; return LRN_OK; }
+  for (int i = 0; i < NSLOT * 16; ++i) hs[i] = 0.0;
   bool use_h = false;
   LRN_TRY(op_select(c, &use_h));
+  const int kind = (c->prec && (c->prec->kind == 1 || c->prec->kind == 2)) ? c->prec->kind : 0;
+  const double* dprec = kind == 2 ? c->prec->d.as<double>() : nullptr;
   LRN_TRY(prec_apply_dev(c, r, z, tmpv));
-  LRN_HIP(c, hipMemcpyAsync(p, z, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-  // The host runs `ahead` iterations in front of the convergence test it has read: the words of iteration `it` are
-  // copied to pinned memory behind its cg_alpha_kernel and looked at while iteration it + ahead is being queued.
+  hipLaunchKernelGGL(cg_d_kernel, dim3(nwg), dim3(256), 0, st, z, r, p, n, per, nwg, scal, rrpart, (const double*)nullptr,
+                     c->pin_dev, 0, residual_0, tol, 1);
+  // The host runs `ahead` iterations in front of the convergence test it has read: the exit words of iteration `it` are
+  // written to host-mapped memory by its kernels and looked at (behind an event) while iteration it + ahead is queued.
   const int ahead = std::max(0, std::min(NSLOT - 2, c->opt.pcg_lookahead));
   int done_code = 0, done_it = 0;
   auto poll = [&](int it) -> int {          // the words of iteration `it`
     const int s = it % NSLOT;
     LRN_HIP(c, hipEventSynchronize(c->pcg_ev[s]));
-    if (hs[s * 16 + 8] != 0.0) { done_code = (int)hs[s * 16 + 8]; done_it = (int)hs[s * 16 + 9]; }
+    if (hs[s * 16] != 0.0) { done_code = (int)hs[s * 16]; done_it = (int)hs[s * 16 + 1]; }
     return LRN_OK;
   };
   int it = 1;
   for (; it <= maxit && done_code == 0; ++it) {
-    LRN_TRY(op_apply(c, use_h, p, Ap));
+    int nq = 0;
+    LRN_TRY(op_apply(c, use_h, p, Ap, qpart, &nq));
     ++nmv;
-    hipLaunchKernelGGL(cg_alpha_kernel, dim3(1), dim3(1024), 0, st, p, Ap, z, r, x, n, scal, it, residual_0, tol);
     const int s = it % NSLOT;
-    LRN_HIP(c, hipMemcpyAsync(hs + s * 16, scal, 10 * 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(cg_b_kernel, dim3(nwg), dim3(256), 0, st, p, Ap, r, x, z, kind, dprec, n, per, scal,
+                       nq > 0 ? qpart : (const double*)nullptr, nq, rrpart, zrpart, c->pin_dev + s * 16, it);
+    if (kind == 1) LRN_TRY(prec_apply_dev(c, r, z, tmpv));
+    hipLaunchKernelGGL(cg_d_kernel, dim3(nwg), dim3(256), 0, st, z, r, p, n, per, nwg, scal, rrpart,
+                       kind == 1 ? (const double*)nullptr : zrpart, c->pin_dev + s * 16, it, residual_0, tol, 0);
     LRN_HIP(c, hipEventRecord(c->pcg_ev[s], st));
     if (it - ahead >= 1) LRN_TRY(poll(it - ahead));
-    if (done_code != 0) break;
-    LRN_TRY(prec_apply_dev(c, r, z, tmpv));
-    hipLaunchKernelGGL(cg_beta_kernel, dim3(1), dim3(1024), 0, st, z, r, p, n, scal);
   }
-  const int last = std::min(it, maxit);
+  const int last = std::min(it - 1, maxit);
   for (int k = std::max(1, last - ahead + 1); k <= last && done_code == 0; ++k) LRN_TRY(poll(k));
   LRN_HIP(c, hipStreamSynchronize(st));
+  LRN_HIP(c, hipGetLastError());
   c->counts["matvec"] += nmv;
   if (done_code != 0) { *exit_code = done_code; *iters = done_it; }
   else { *exit_code = -2; *iters = maxit; }

@@ -86,6 +86,42 @@ int comm_allgather(lrn_ctx* c, const double* send, double* recv, long count) {
   return LRN_OK;
 }
 
+// Column blocks of an n x n column-major matrix, in place: rank r holds columns [r cb, min(n, (r + 1) cb)) and receives
+// the others (the sharded n^3 products of the resident path, prepw.hip::pgemm_nt).  RCCL: one broadcast per rank inside a
+// group (the last block may be narrower); host transport: packed through the equal-count all-gather callback.
+int comm_allgather_cols(lrn_ctx* c, double* C, int n, int cb) {
+  Comm* m = c->comm;
+  if (!m || m->world <= 1) return LRN_OK;
+  m->calls += 1;
+  if (m->nccl) {
+    ncclResult_t r = ncclGroupStart();
+    for (int k = 0; k < m->world && r == ncclSuccess; ++k) {
+      const long c0 = std::min<long>(n, (long)k * cb), c1 = std::min<long>(n, c0 + cb);
+      if (c1 > c0) r = ncclBroadcast(C + c0 * n, C + c0 * n, (size_t)((c1 - c0) * n), ncclDouble, k, m->nccl, c->stream);
+    }
+    const ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess) return nccl_fail(c, r, "ncclBroadcast");
+    if (r2 != ncclSuccess) return nccl_fail(c, r2, "ncclGroupEnd");
+    return LRN_OK;
+  }
+  const long per = (long)cb * n;
+  LRN_TRY(ensure(c, m->pack, (size_t)per * 8));
+  LRN_TRY(ensure(c, m->gathered, (size_t)per * m->world * 8));
+  const long c0 = std::min<long>(n, (long)m->rank * cb), c1 = std::min<long>(n, c0 + cb);
+  LRN_HIP(c, hipMemsetAsync(m->pack.p, 0, (size_t)per * 8, c->stream));
+  if (c1 > c0)
+    LRN_HIP(c, hipMemcpyAsync(m->pack.p, C + c0 * n, (size_t)((c1 - c0) * n) * 8, hipMemcpyDeviceToDevice, c->stream));
+  LRN_TRY(comm_allgather(c, m->pack.as<double>(), m->gathered.as<double>(), per));
+  for (int k = 0; k < m->world; ++k) {
+    if (k == m->rank) continue;
+    const long k0 = std::min<long>(n, (long)k * cb), k1 = std::min<long>(n, k0 + cb);
+    if (k1 > k0)
+      LRN_HIP(c, hipMemcpyAsync(C + k0 * n, m->gathered.as<double>() + (long)k * per, (size_t)((k1 - k0) * n) * 8,
+                                hipMemcpyDeviceToDevice, c->stream));
+  }
+  return LRN_OK;
+}
+
 // a few status words, max-reduced over the ranks (host in, host out; every rank must call it)
 int comm_status_max(lrn_ctx* c, double* words, int nw) {
   Comm* m = c->comm;

@@ -23,6 +23,9 @@ struct LmiBlock {
   lrn::DBuf ent_r, ent_c;   // int32 [nent]
   lrn::DBuf ent_v;          // double [nent]   value of A_j (= -AA)
   lrn::DBuf Adense;         // double [nd * msz^2], slot s = position s
+  int dense_sym = -1;       // every dense constraint matrix is exactly symmetric: -1 not checked yet, 0 no, 1 yes
+  lrn::DBuf tri_tab;        // chunk table of the half-traffic passes over the dense data (cgops.hip::TriChunk)
+  int tri_nch = 0;
   lrn::DBuf hidx;           // int32 [nvar] position -> row/col index of the Schur matrix
   lrn::DBuf sigma_d, ipos_d; // int32 [nvar] device copies of sigma / ipos
   // stored columns of AA (sparse constraints only) for the deterministic AA'x gather
@@ -104,6 +107,9 @@ struct LrnOptions {
   int lyap_maxit = 300;
   int pair_lanes = 0;             // pair_wave_kernel: lanes per Schur entry, 0 auto (16 for short products), 16, 64
   int matvec_sparse = 0;          // 0 auto, 1 dense GEMM path, 2 sparse path whenever the pattern allows
+  int shard_products = 1;         // multi-GPU: the n^3 products of the resident path (Newton-Schulz, Lyapunov CG, step) by
+  int shard_products_min = 4096;  // column blocks + all-gather from this matrix side on (one product of 10^4: 31 ms; below, the
+                                  // all-gather costs more than the product)
   int matvec_h = 0;               // CG operator through the assembled Schur matrix (hop.hip): 0 auto (cost model), 1 never
                                   // (the matrix-free MyA always), 2 always
   int pcg_lookahead = 2;          // lrn_pcg: iterations the host queues beyond the one whose convergence test it has read
@@ -149,7 +155,9 @@ struct lrn_ctx {
   bool hop_use = false;
   long cg_cur_iters = 0, cg_prev_iters = 0;
   lrn::DBuf hopbuf;           // partial sums of the triangular mat-vec
-  double* pin = nullptr;      // pinned host words: convergence read-back of lrn_pcg
+  double* pin = nullptr;      // host-mapped words the CG kernels write their exit code to (lrn_pcg), and their device address
+  double* pin_dev = nullptr;
+  lrn::DBuf cgpart;           // partial sums of the CG recurrence kernels
   hipEvent_t pcg_ev[16] = {};
   // assembly workspaces
   lrn::DBuf P, P2, T, slabs, Hd, BG;
@@ -171,6 +179,7 @@ struct lrn_ctx {
   hipEvent_t evC = nullptr, evD = nullptr;
   // generic scratch
   lrn::DBuf scratch, jscratch, redbuf, redout, lzbuf, lzbuf2, lxbuf, ezbuf;
+  lrn::DBuf triw;               // tri-weights of the matrices the dense passes multiply with (2 msz^2)
   lrn::DBuf commvec, commmat;   // multi-GPU: partial results of the sharded passes over dense constraint data
   // preconditioner / CG state
   lrn::Prec* prec = nullptr;
@@ -191,6 +200,7 @@ void toc(lrn_ctx* c, const char* key);
 // comm.hip
 int comm_allreduce(lrn_ctx* c, double* buf_dev, long count, int op);     // in place on c->stream; op 0 sum, 1 min, 2 max
 int comm_allgather(lrn_ctx* c, const double* send_dev, double* recv_dev, long count);
+int comm_allgather_cols(lrn_ctx* c, double* C_dev, int n, int cb);   // column blocks of width cb of an n x n matrix, in place
 int comm_schur_exchange(lrn_ctx* c, int rc_local, bool gather_blocks = true);
 int comm_agree_plan(lrn_ctx* c, int mode);
 int comm_status_max(lrn_ctx* c, double* words, int nw);
@@ -204,7 +214,8 @@ int schur_solve(lrn_ctx* c, const double* h, double* dely);
 int schur_add_diag(lrn_ctx* c, double eps);
 int schur_get(lrn_ctx* c, double* Hout);
 // hop.hip: the CG operator through the assembled matrix
-int hop_apply(lrn_ctx* c, const double* x_dev, double* y_dev);
+// y = H x; qpart (may be null): receives *nq partial sums of x'y (*nq = 0: not formed, e.g. sharded)
+int hop_apply(lrn_ctx* c, const double* x_dev, double* y_dev, double* qpart = nullptr, int* nq = nullptr);
 bool hop_worthwhile(lrn_ctx* c, long expected_iters);
 int hop_prepare(lrn_ctx* c);
 }  // namespace lrn

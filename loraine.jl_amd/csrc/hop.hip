@@ -147,23 +147,45 @@ __global__ __launch_bounds__(256) void symv_lower_tiles_kernel(const double* __r
     if (r0 + i < n) rowout[r0 + i] = (rsum[0][i] + rsum[1][i]) + (rsum[2][i] + rsum[3][i]);
 }
 
-// y[idx[i]] = sum of the partials of row / column i, fixed order
+// y[idx[i]] = sum of the partials of row / column i in a fixed order: 64 outputs per workgroup, the slabs dealt to
+// the four waves (slab s to wave s % 4), the four sums added through LDS.  qpart (may be null): per-workgroup partial
+// sums of x[idx[i]] y[idx[i]] -- the p'Ap of the CG iteration without another pass over the vectors.
 __global__ __launch_bounds__(256) void symv_lower_reduce_kernel(const double* __restrict__ colpart,
                                                                 const double* __restrict__ rowpart, int n, int RB,
-                                                                const int* __restrict__ idx, double* __restrict__ y,
+                                                                const int* __restrict__ idx, const double* __restrict__ x,
+                                                                double* __restrict__ y, double* __restrict__ qpart,
                                                                 int rank, int world, int shard_bs) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int nrb = (n + RB - 1) / RB;
-  const int J = i >> 7;
+  __shared__ double sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   double s = 0.0;
-  if (world <= 1 || shard_owner((J * 128) / shard_bs, world) == rank)
-    for (int I = (J * 128) / RB; I < nrb; ++I) s += colpart[(size_t)I * n + i];
-  const int Jmax = min((n - 1) >> 7, ((i / RB) * RB + RB - 1) >> 7);
-  double s2 = 0.0;
-  for (int Jc = 0; Jc <= Jmax; ++Jc)
-    if (world <= 1 || shard_owner((Jc * 128) / shard_bs, world) == rank) s2 += rowpart[(size_t)Jc * n + i];
-  y[idx ? idx[i] : i] = s + s2;
+  if (i < n) {
+    const int nrb = (n + RB - 1) / RB;
+    const int J = i >> 7;
+    const int I0 = (J * 128) / RB;
+    const int ncol = (world <= 1 || shard_owner((J * 128) / shard_bs, world) == rank) ? nrb - I0 : 0;
+    const int Jmax = min((n - 1) >> 7, ((i / RB) * RB + RB - 1) >> 7);
+    // unified slab list: [0, ncol) column slabs I0 + k, then the row slabs 0 .. Jmax
+    for (int k = w; k < ncol; k += 4) s += colpart[(size_t)(I0 + k) * n + i];
+    for (int k = ((w - ncol) % 4 + 4) % 4; k <= Jmax; k += 4)
+      if (world <= 1 || shard_owner((k * 128) / shard_bs, world) == rank) s += rowpart[(size_t)k * n + i];
+  }
+  sh[w][lane] = s;
+  __syncthreads();
+  if (w == 0) {
+    double v = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    double q = 0.0;
+    if (i < n) {
+      const int o = idx ? idx[i] : i;
+      y[o] = v;
+      q = x[o] * v;
+    }
+    if (qpart) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+      if (lane == 0) qpart[blockIdx.x] = q;
+    }
+  }
 }
 
 static bool hop_shardable(const lrn_ctx* c) {
@@ -172,7 +194,7 @@ static bool hop_shardable(const lrn_ctx* c) {
 
 // y = H x (natural constraint order on both sides; H lives in sigma-position space when nlmi == 1).  world > 1: this
 // rank's column chunks only, the caller all-reduces.
-int hop_apply(lrn_ctx* c, const double* x, double* y) {
+int hop_apply(lrn_ctx* c, const double* x, double* y, double* qpart, int* nq) {
   const int n = c->nvar;
   if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
   const bool small = n < 8192;
@@ -193,8 +215,11 @@ int hop_apply(lrn_ctx* c, const double* x, double* y) {
   if (small) { if (vec2) LRN_SYMV(1, true); else LRN_SYMV(1, false); }
   else { if (vec2) LRN_SYMV(4, true); else LRN_SYMV(4, false); }
 #undef LRN_SYMV
-  hipLaunchKernelGGL(symv_lower_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, colpart, rowpart, n, RB,
-                     idx, y, rank, world, c->shard_bs);
+  // (sharded: the partial products x'y would be those of this rank's share -- the caller forms the dot after the all-reduce)
+  double* qp = sharded ? nullptr : qpart;
+  hipLaunchKernelGGL(symv_lower_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, c->stream, colpart, rowpart, n, RB,
+                     idx, x, y, qp, rank, world, c->shard_bs);
+  if (nq) *nq = qp ? (n + 63) / 64 : 0;
   c->counts["hop_matvec"] += 1;
   return LRN_OK;
 }

@@ -742,7 +742,7 @@ static int lyap_solve(lrn_ctx* c, LmiBlock& b, double* Cm, double* R, double* wo
   while (k < maxit) {
     const int k1 = std::min(maxit, k + (k == 0 ? 8 : 4));
     for (; k < k1; ++k) {
-      LRN_TRY(gemm_nt(st, n, b.Yh.as<double>(), p, work));
+      LRN_TRY(pgemm_nt(c, st, n, b.Yh.as<double>(), p, work));
       hipLaunchKernelGGL(symadd_kernel, dim3(np1), dim3(256), 0, st, work, n, 1.0, Ap, p, part1);
       hipLaunchKernelGGL(lyap_xr_kernel, dim3(np), dim3(256), 0, st, part1, np1, hist, k, p, Ap, R, r, nn, part2);
       hipLaunchKernelGGL(lyap_p_kernel, dim3(np), dim3(256), 0, st, part2, np, hist, k, r, p, nn);
@@ -843,6 +843,7 @@ extern "C" int lrn_ip_residual_d(lrn_ctx* c, const double* y) {
   if (!c || !y) return LRN_ERR_ARG;
   LRN_HIP(c, hipSetDevice(c->device));
   LRN_TRY(copy_in(c, c->v0.p, y, (size_t)c->nvar * 8));
+  tic(c);
   for (auto& b : c->lmi) {
     LRN_TRY(ensure_resident(c, b));
     const long mm_ = (long)b.msz * b.msz;
@@ -850,6 +851,7 @@ extern "C" int lrn_ip_residual_d(lrn_ctx* c, const double* y) {
     hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.Rd.as<double>(), 1.0, b.Cd.as<double>(),
                        -1.0, b.S.as<double>(), -1.0, b.t0.as<double>(), mm_);
   }
+  toc(c, "residual_d");
   return LRN_OK;
 }
 
@@ -874,6 +876,7 @@ extern "C" int lrn_ip_rhs_pred2(lrn_ctx* c, double* aax_out, double* out) {
   LRN_HIP(c, hipSetDevice(c->device));
   const int n = c->nvar;
   LRN_TRY(ensure(c, c->v2, (size_t)(n + 64) * 8));
+  tic(c);
   LRN_HIP(c, hipMemsetAsync(c->v1.p, 0, (size_t)n * 8, c->stream));
   LRN_HIP(c, hipMemsetAsync(c->v2.p, 0, (size_t)n * 8, c->stream));
   for (auto& b : c->lmi) {
@@ -884,6 +887,7 @@ extern "C" int lrn_ip_rhs_pred2(lrn_ctx* c, double* aax_out, double* out) {
     LRN_TRY(wmw(c, b, b.t0.as<double>(), b.t1.as<double>(), b.t2.as<double>()));
     LRN_TRY(aa_times2(c, b, b.X.as<double>(), c->v2.as<double>(), b.t2.as<double>(), c->v1.as<double>()));
   }
+  toc(c, "rhs");
   LRN_TRY(copy_out(c, aax_out, c->v2.p, (size_t)n * 8));
   return copy_out(c, out, c->v1.p, (size_t)n * 8);
 }
@@ -892,6 +896,7 @@ extern "C" int lrn_ip_rhs_corr(lrn_ctx* c, double sigma_mu, double* out) {
   if (!c || !out) return LRN_ERR_ARG;
   LRN_HIP(c, hipSetDevice(c->device));
   const int n = c->nvar;
+  tic(c);
   LRN_HIP(c, hipMemsetAsync(c->v1.p, 0, (size_t)n * 8, c->stream));
   for (auto& b : c->lmi) {
     LRN_TRY(ensure_resident(c, b));
@@ -918,6 +923,7 @@ extern "C" int lrn_ip_rhs_corr(lrn_ctx* c, double sigma_mu, double* out) {
     LRN_TRY(mm(c, m, b.t1.as<double>(), false, G, true, b.t2.as<double>()));
     LRN_TRY(aa_times(c, b, b.t2.as<double>(), c->v1.as<double>()));
   }
+  toc(c, "rhs");
   return copy_out(c, out, c->v1.p, (size_t)n * 8);
 }
 
@@ -946,17 +952,17 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
       // everything in the L_X basis (prepw.hip::prepare_w_ns): Bs = L_X' dS L_X, T = Z Bs Z / c,
       // TX = L_X^-1 dX L_X^-T = -I - T (+ sigma_mu K^-1 + R), dX = L_X TX L_X'                  (:253-257)
       const unsigned gs = (unsigned)std::min<long>(1024, ((long)(m + 31) / 32) * ((m + 31) / 32));
-      LRN_TRY(gemm_nt(c->stream, m, b.LXt.as<double>(), b.delS.as<double>(), t0));
-      LRN_TRY(gemm_nt(c->stream, m, t0, b.LXt.as<double>(), t1));
+      LRN_TRY(pgemm_nt(c, c->stream, m, b.LXt.as<double>(), b.delS.as<double>(), t0));
+      LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.LXt.as<double>(), t1));
       hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, b.Bs.as<double>(), (const double*)nullptr,
                          (double*)nullptr);
-      LRN_TRY(gemm_nt(c->stream, m, b.Zh.as<double>(), b.Bs.as<double>(), t0));
-      LRN_TRY(gemm_nt(c->stream, m, t0, b.Zh.as<double>(), t1, 0, 1.0 / b.ns_c));
+      LRN_TRY(pgemm_nt(c, c->stream, m, b.Zh.as<double>(), b.Bs.as<double>(), t0));
+      LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.Zh.as<double>(), t1, 0, 1.0 / b.ns_c));
       hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, t3, (const double*)nullptr, (double*)nullptr);
       hipLaunchKernelGGL(tx_kernel, dim3(g), dim3(256), 0, c->stream, t3, sigma_mu / b.ns_c, b.Ki.as<double>(),
                          predict ? (const double*)nullptr : b.RNT.as<double>(), b.TX.as<double>(), m);
-      LRN_TRY(gemm_nt(c->stream, m, b.LXf.as<double>(), b.TX.as<double>(), t0));
-      LRN_TRY(gemm_nt_sym(c->stream, m, t0, b.LXf.as<double>(), b.delX.as<double>(), 1.0));
+      LRN_TRY(pgemm_nt(c, c->stream, m, b.LXf.as<double>(), b.TX.as<double>(), t0));
+      LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXf.as<double>(), b.delX.as<double>(), 1.0));
       // the scaled directions of the step-length rule are orthogonally similar to TX and T               (:263-285)
       LRN_TRY(eigmin_certified_pair(c, b.TX.as<double>(), t3, m, &lamX, &lamS));
       alpha[il] = lamX > -1e-6 ? 0.99 : std::min(1.0, -tau / lamX);
@@ -1020,8 +1026,8 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
         // Qm = G RNT G' without the eigenvectors: N = L_X^-1 dX dS L_X = TX Bs, Yh R + R Yh = -(N Zh + Zh N') / c,
         // Qm = L_X R L_X'
         tic(c);
-        LRN_TRY(gemm_nt(c->stream, m, b.TX.as<double>(), b.Bs.as<double>(), t0));              // N
-        LRN_TRY(gemm_nt(c->stream, m, t0, b.Zh.as<double>(), t1));                             // N Zh
+        LRN_TRY(pgemm_nt(c, c->stream, m, b.TX.as<double>(), b.Bs.as<double>(), t0));              // N
+        LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.Zh.as<double>(), t1));                             // N Zh
         hipLaunchKernelGGL(symadd_kernel, dim3((unsigned)std::min<long>(1024, ((long)(m + 31) / 32) * ((m + 31) / 32))), dim3(256), 0,
                            c->stream, t1, m, -1.0 / b.ns_c, t2, (const double*)nullptr, (double*)nullptr);
         bool ok = false;
@@ -1030,8 +1036,8 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
         c->counts["lyap_steps"] += steps;
         c->counts["lyap_solves"] += 1;
         if (ok) {
-          LRN_TRY(gemm_nt(c->stream, m, b.LXf.as<double>(), b.RNT.as<double>(), t0));
-          LRN_TRY(gemm_nt_sym(c->stream, m, t0, b.LXf.as<double>(), b.Qm.as<double>(), 1.0));
+          LRN_TRY(pgemm_nt(c, c->stream, m, b.LXf.as<double>(), b.RNT.as<double>(), t0));
+          LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXf.as<double>(), b.Qm.as<double>(), 1.0));
           toc(c, "lyap");
           continue;
         }

@@ -159,6 +159,7 @@ __global__ void build_constraint_kernel(const long* __restrict__ ptr, const int*
 using namespace lrn;
 
 static void free_block(LmiBlock& b) {
+  release(b.tri_tab);
   for (DBuf* d : {&b.ent_ptr, &b.ent_r, &b.ent_c, &b.ent_v, &b.Adense, &b.hidx, &b.sigma_d, &b.ipos_d, &b.cq_q, &b.cq_ptr, &b.cq_j, &b.cq_v, &b.pc_ptr, &b.pc_r, &b.pc_t, &b.ent_t, &b.Mv, &b.Zs, &b.b_ptr, &b.b_col,
                   &b.b_val, &b.X, &b.S, &b.W, &b.G, &b.Gi, &b.Si, &b.D, &b.DDsi, &b.Vprev, &b.Cd, &b.Rd, &b.delX, &b.delS, &b.Xn, &b.Sn, &b.RNT,
                   &b.t0, &b.t1, &b.t2, &b.LXf, &b.LXt, &b.LSf, &b.Yh, &b.Zh, &b.Ki, &b.Bs, &b.TX, &b.Qm, &b.lyap, &b.Bd})
@@ -509,6 +510,7 @@ extern "C" int lrn_synthetic_dense_model(lrn_ctx* c, int msz, int nvar, uint64_t
   b.nnz.assign(nvar, (long)msz * msz);
   b.qA = b.nd = b.q_wave = b.npos_nz = nvar;
   b.sp_ok = false;
+  b.dense_sym = 1;          // (R_k + R_k')/2 from one Philox draw per unordered index pair: symmetric by construction
   b.nent = 0;
   std::vector<long> ptr(nvar + 1, 0);
   LRN_TRY(ensure(c, b.ent_ptr, (size_t)(nvar + 1) * 8));

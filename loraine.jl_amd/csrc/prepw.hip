@@ -369,6 +369,44 @@ int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double
   return LRN_OK;
 }
 
+bool products_sharded(const lrn_ctx* c, hipStream_t st, int n) {
+  return c->comm && c->world > 1 && c->opt.shard_products != 0 && st == c->stream && n >= c->opt.shard_products_min;
+}
+
+static int shard_cols(const lrn_ctx* c, int n, int* c0, int* c1) {
+  const int cb = (((n + c->world - 1) / c->world) + 15) & ~15;      // 16-column granularity: aligned operand pointers
+  *c0 = std::min(n, c->rank * cb);
+  *c1 = std::min(n, *c0 + cb);
+  return cb;
+}
+
+int pgemm_nt(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags, double alpha,
+             double* Ct) {
+  if (flags != 0 || !products_sharded(c, st, n)) return gemm_nt(st, n, A, Bm, C, flags, alpha, Ct);
+  int c0, c1;
+  const int cb = shard_cols(c, n, &c0, &c1);
+  if (c1 > c0) {
+    GemmDesc g;                      // C[:, c0:c1] = alpha A Bm[c0:c1, :]'
+    g.A = A; g.sAm = 1; g.sAk = n;
+    g.B = Bm + c0; g.sBk = n; g.sBn = 1;
+    g.C = C + (long)c0 * n; g.sCm = 1; g.sCn = n;
+    g.M = n; g.N = c1 - c0; g.K = n;
+    g.alpha = alpha;
+    LRN_TRY(gemm(st, g));
+  }
+  LRN_TRY(comm_allgather_cols(c, C, n, cb));
+  c->counts["pgemm_sharded"] += 1;
+  if (Ct) hipLaunchKernelGGL(transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, st, C, n, Ct);
+  return LRN_OK;
+}
+
+int pgemm_nt_sym(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha) {
+  if (!products_sharded(c, st, n)) return gemm_nt_sym(st, n, A, Bm, C, alpha);
+  LRN_TRY(pgemm_nt(c, st, n, A, Bm, C, 0, alpha, nullptr));
+  hipLaunchKernelGGL(sym_inplace_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, C, n);
+  return LRN_OK;
+}
+
 // smallest pivot of a Cholesky factor: out = min_i L_ii^2
 __global__ __launch_bounds__(256) void min_pivot_kernel(const double* __restrict__ L, int n, double* __restrict__ out) {
   __shared__ double sh[4];
@@ -479,7 +517,10 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   double* res = part + npart;        // res[0..maxit), then sc[0..1]
   double* sc = res + maxit;
   double *LX = b.LXf.as<double>(), *LS = b.LSf.as<double>();
-  hipStream_t s2 = c->opt.prepw_streams ? c->stream2 : st;
+  // (sharded products carry collectives: everything on the context's stream then, the order of the calls is the order of
+  // the collectives on every rank)
+  const bool shp = products_sharded(c, st, n);
+  hipStream_t s2 = (c->opt.prepw_streams && !shp) ? c->stream2 : st;
   const bool two = s2 != st;
   const unsigned ge = nb2((long)nn);
   if (two) {
@@ -492,9 +533,15 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LS, n, LSt);
   if (two) LRN_HIP(c, hipEventRecord(c->evB, s2));
   hipLaunchKernelGGL(eye_kernel, dim3(ge), dim3(256), 0, s2, LSi, n);
+  if (shp) {                                          // L_S^-1: each rank solves its block of the identity's columns
+    int c0, c1;
+    const int cb = shard_cols(c, n, &c0, &c1);
+    if (c1 > c0) LRN_TRY(trsm_left_lower(s2, LS, n, n, nullptr, false, LSi + (long)c0 * n, c1 - c0, n, tw2));
+    LRN_TRY(comm_allgather_cols(c, LSi, n, cb));
+  } else
   LRN_TRY(trsm_left_lower(s2, LS, n, n, nullptr, false, LSi, n, n, tw2));
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LSi, n, LSit);   // L_S^-T
-  LRN_TRY(gemm_nt_sym(s2, n, LSit, LSit, b.Si.as<double>(), 1.0));
+  LRN_TRY(pgemm_nt_sym(c, s2, n, LSit, LSit, b.Si.as<double>(), 1.0));
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, LX, n, LXt);
   // K = CC' CC with CC = L_S' L_X (prepare_W.jl:39) -- NOT L_X' S L_X: with cond(X), cond(S) at 1e10 the entries of
   // |L_X'| |S| |L_X| are 1e10 times those of K and the explicit product has no correct digit left (measured: the
@@ -502,8 +549,8 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   double* Y = b.Yh.as<double>();
   double* Z = b.Zh.as<double>();
   if (two) LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
-  LRN_TRY(gemm_nt(st, n, LXt, LSt, Pm, 0, 1.0));                                      // CC' = L_X' L_S
-  LRN_TRY(gemm_nt_sym(st, n, Pm, Pm, Tm, 1.0));                                        // K = CC' CC
+  LRN_TRY(pgemm_nt(c, st, n, LXt, LSt, Pm, 0, 1.0));                                      // CC' = L_X' L_S
+  LRN_TRY(pgemm_nt_sym(c, st, n, Pm, Pm, Tm, 1.0));                                        // K = CC' CC
   hipLaunchKernelGGL(colnorm_kernel, dim3(n), dim3(256), 0, st, Tm, n, colsum, colsq);
   hipLaunchKernelGGL(normc_kernel, dim3(1), dim3(256), 0, st, colsum, colsq, n, sc);
   hipLaunchKernelGGL(scale_dev_kernel, dim3(ge), dim3(256), 0, st, Tm, sc, (long)nn, Y);
@@ -520,15 +567,15 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   // the 64-tile kernel) or by a transpose pass of its own (8 us there)
   const bool dual = c->opt.ns_dual == 1 || (c->opt.ns_dual < 0 && n >= 1500);
   auto prod = [&](hipStream_t sx, const double* A, const double* Bm, double* C, double* Ct) -> int {
-    if (dual) return gemm_nt(sx, n, A, Bm, C, 0, 1.0, Ct);
-    LRN_TRY(gemm_nt(sx, n, A, Bm, C, 0, 1.0));
+    if (dual) return pgemm_nt(c, sx, n, A, Bm, C, 0, 1.0, Ct);
+    LRN_TRY(pgemm_nt(c, sx, n, A, Bm, C, 0, 1.0));
     hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, sx, C, n, Ct);
     return LRN_OK;
   };
   // Y T and T Z are independent: the second one on a third stream, so that two workgroups share every CU where one
   // product alone (256 tiles of 128 at msz 2000) leaves each CU a single workgroup
   hipStream_t s3 = st;
-  if (c->opt.prepw_streams && n >= 1024) {
+  if (c->opt.prepw_streams && n >= 1024 && !shp) {
     if (!c->stream3) {
       LRN_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
       LRN_HIP(c, hipEventCreateWithFlags(&c->evC, hipEventDisableTiming));
@@ -541,7 +588,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
     // symmetric and Y T, T Z taken literally the iteration stays stable (residual floor 1e-12 instead of 1e-13, NumPy and
     // device) -- and T is its own transposed twin
     const double* Pk = Yc;                                // Z = I: P = Y (exactly symmetric)
-    if (!z_is_eye) { LRN_TRY(gemm_nt_sym(st, n, Zc, Ytc, Pm, 1.0)); Pk = Pm; }
+    if (!z_is_eye) { LRN_TRY(pgemm_nt_sym(c, st, n, Zc, Ytc, Pm, 1.0)); Pk = Pm; }
     hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Pk, n, a, Tm, part);
     hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, part, npart, res + k);
     double* const Tt = Tm;
@@ -602,10 +649,10 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   if (Yc != Y) LRN_HIP(c, hipMemcpyAsync(Y, Yc, mm, hipMemcpyDeviceToDevice, st));
   if (Zc != Z) LRN_HIP(c, hipMemcpyAsync(Z, Zc, mm, hipMemcpyDeviceToDevice, st));
   // W = L_X K^-1/2 L_X' = L_X Z L_X' / sqrt(c)                                          (prepare_W.jl:64)
-  LRN_TRY(gemm_nt(st, n, LX, Ztc, Pm, 0, 1.0));
-  LRN_TRY(gemm_nt_sym(st, n, Pm, LX, b.W.as<double>(), 1.0 / std::sqrt(b.ns_c)));
+  LRN_TRY(pgemm_nt(c, st, n, LX, Ztc, Pm, 0, 1.0));
+  LRN_TRY(pgemm_nt_sym(c, st, n, Pm, LX, b.W.as<double>(), 1.0 / std::sqrt(b.ns_c)));
   // (K/c)^-1 = Zh^2: the sigma_mu S^-1 term of the corrector in the L_X basis
-  LRN_TRY(gemm_nt(st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
+  LRN_TRY(pgemm_nt(c, st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
   if (two) {                                                  // join: Si is complete when this returns
     LRN_HIP(c, hipEventRecord(c->evB, s2));
     LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));

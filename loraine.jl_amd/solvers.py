@@ -490,6 +490,8 @@ class MySolver:
                             factor=d.timing("factor"), solve=d.timing("solve"),
                             prec_setup=d.timing("prec_setup"), pcg=d.timing("pcg"), svd=d.timing("prepw_svd")),
                 svd_sweeps=d.count("svd_sweeps"), find_step_ms=d.timing("find_step"),
+                rhs_ms=d.timing("rhs"), residual_d_ms=d.timing("residual_d"), stats_ms=d.timing("stats"),
+                hop_assemble=d.count("hop_assemble"), hop_matvec=d.count("hop_matvec"),
                 ns_steps=d.count("ns_steps"), lyap_steps=d.count("lyap_steps"), lyap_ms=d.timing("lyap"),
                 ns_fallback=d.count("ns_fallback"), lyap_fallback=d.count("lyap_fallback"),
                 lanczos_steps=d.count("lanczos_steps"), lanczos_runs=d.count("lanczos_runs"),

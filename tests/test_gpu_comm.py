@@ -41,14 +41,30 @@ def _worker(rank, world, port, out_dir):
              ("theta1_cg", lambda: model_from_sdpa(os.path.join(GOLD, "theta1.dat-s")),
               dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5)),
              ("lowrank_cg", lambda: LowRankProblem(60, 120, 4, seed=7).model(), dict(kit=1, preconditioner=2, erank=4, eDIMACS=1e-6))]
-    for name, mk, opts in cases:
+    # round 4: the CG operator through the assembled Schur matrix, every rank multiplying the column blocks it assembled
+    # (matvec_h = 2 forces it at this size); the n^3 products of the resident path (Newton-Schulz, Lyapunov CG, step) as
+    # column blocks + all-gather (shard_products_min lowered to this size)
+    cases += [("lowrank_cg_h", lambda: LowRankProblem(60, 120, 4, seed=7).model(),
+               dict(kit=1, preconditioner=2, erank=4, eDIMACS=1e-6), dict(matvec_h=2)),
+              ("theta1_products", lambda: model_from_sdpa(os.path.join(GOLD, "theta1.dat-s")), dict(kit=0, eDIMACS=1e-6),
+               dict(shard_products_min=16)),
+              ("lowrank_products", lambda: LowRankProblem(60, 120, 4, seed=7).model(),
+               dict(kit=1, preconditioner=2, erank=4, eDIMACS=1e-6), dict(shard_products_min=16, matvec_h=2))]
+    for name, mk, opts, *lib in cases:
         model = mk()
+        libopts = lib[0] if lib else {}
+        for k, v in libopts.items():
+            dev.set_option(k, v)
+        dev.reset_timing()
         solver, ha = resident.load(model, dict(opts, verb=0), device=dev)
         hot = DistributedHotPath(solver, rank, world)
         solver.solve(ha)
         out[name] = dict(status=solver.status, iters=solver.iter, obj=-(float(model.b @ np.ravel(solver.y)) - model.b_const),
-                         transport=getattr(hot, "transport", None), exchanges=dev.count("exchange"))
+                         transport=getattr(hot, "transport", None), exchanges=dev.count("exchange"),
+                         hop=dev.count("hop_matvec"), pgemm=dev.count("pgemm_sharded"))
         dev.comm_destroy()
+        for k in libopts:
+            dev.set_option(k, dict(matvec_h=0, shard_products_min=4096)[k])
     # dense data: the Cholesky path splits the columns of the matrix variable, the exchange is an all-reduce
     dev.set_option("schur_chol", 1)            # (auto takes the path from msz 256 on)
     solver, ha = synthetic_dense_solver(dev, DENSE_MSZ, 160, seed=11, options=dict(kit=0, verb=0))
@@ -76,6 +92,13 @@ def test_two_ranks_on_one_gpu_solve_through_the_library_communicator(tmp_path):
         assert r[0][name]["iters"] == r[1][name]["iters"]
     assert r[0]["theta1"]["exchanges"] > 0                         # one exchange per assembly, inside lrn_schur_assemble
     assert r[0]["lowrank_cg"]["status"] == 1 and r[0]["lowrank_cg"]["obj"] == r[1]["lowrank_cg"]["obj"]
+    # round 4 (see _worker): both ranks in lock-step, the sharded code ran, the optimum is that of the plain two-rank run
+    for name, twin in (("lowrank_cg_h", "lowrank_cg"), ("theta1_products", "theta1"), ("lowrank_products", "lowrank_cg")):
+        assert r[0][name]["status"] == 1 and r[0][name]["obj"] == r[1][name]["obj"] and r[0][name]["iters"] == r[1][name]["iters"]
+        assert r[0][name]["obj"] == pytest.approx(r[0][twin]["obj"], rel=1e-7)
+    assert r[0]["lowrank_cg_h"]["hop"] > 0 and r[1]["lowrank_cg_h"]["hop"] > 0
+    assert r[0]["theta1_products"]["pgemm"] > 0 and r[0]["lowrank_products"]["pgemm"] > 0
+    assert r[0]["theta1_products"]["iters"] == r[0]["theta1"]["iters"]
     assert r[0]["dense"]["status"] == 1 and r[0]["dense"]["obj"] == r[1]["dense"]["obj"]
     assert r[0]["dense"]["iters"] == r[1]["dense"]["iters"]
     # the same dense problem on ONE rank (here, in the parent): the two-rank run -- column split of the assembly, the passes

@@ -166,8 +166,8 @@ def _random_model(m, nvar, seed):
 @pytest.mark.parametrize("nt_mode", [1, 0])
 @pytest.mark.parametrize("cond", [1e6, 1e9, 1e12])
 def test_one_iteration_function_by_function_on_ill_conditioned_iterates(dev, cond, nt_mode):
-    """Synthetic X, S with cond(X) = cond(S) from 1e6 to 1e12.  The oracle's own SVD route loses cond * eps here: the
-    tolerance of the scaling is the identity W S W = X to 1e-16 cond (1e-10 at least), of the step 10 x that."""
+    """Synthetic X, S with cond(X) = cond(S) from 1e6 to 1e12.  The oracle's own SVD route loses cond * eps here (both device
+    routes sit at the same distance from it): tolerance of the scaling 1e-16 cond (1e-10 at least), of the step 4 x that."""
     m, nvar = 96, 40
     model = _random_model(m, nvar, 3)
     X, S = _near_central_path(m, cond, 11)
@@ -177,8 +177,8 @@ def test_one_iteration_function_by_function_on_ill_conditioned_iterates(dev, con
         e = _device_step(dev, model, X, S, y, st, nt_mode)
     finally:
         dev.set_option("nt_mode", 1)
-    tol = max(1e-10, 1e-16 * cond * 10)
-    _check(e, tol, max(1e-9, 10 * tol), f"cond={cond:g} nt_mode={nt_mode}")
+    tol = max(1e-10, 1e-16 * cond)          # measured 2e-11 / 1.3e-8 / 1.6e-5 at cond 1e6 / 1e9 / 1e12, the same on both routes
+    _check(e, tol, max(1e-9, 4 * tol), f"cond={cond:g} nt_mode={nt_mode}")
 
 
 def _run(path, device, **opts):

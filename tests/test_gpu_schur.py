@@ -627,3 +627,41 @@ def test_gemm3_last_tile_row_of_height_160(dev, nvar):
     A = np.stack([dev.get_constraint(0, int(k)) for k in idx])
     Hfull = Hs[0] + np.tril(Hs[0], -1).T
     assert relerr(Hfull[np.ix_(idx, idx)], _brute_H(A, W)) < 1e-13
+
+
+@pytest.mark.parametrize("msz,nvar,mixed", [(256, 30, False), (258, 21, False), (300, 23, True), (272, 9, False)])
+def test_dense_passes_over_the_column_tails(dev, msz, nvar, mixed):
+    """The passes over dense constraint data read only the column tails rows >= j of the symmetric matrices (round 4):
+    AA*vec(Z) with the weights Z + Z' (makeRHS, src/makeBBBB.jl:221-228; Z deliberately NOT symmetric: <A_k, Z> =
+    <A_k, sym Z> must come out), and mat(AA'x) as the mirrored lower triangle (src/Solvers.jl:595; with sparse constraints
+    beside the dense ones when `mixed`).  msz 258 / 300 / 272: tails that do not end on a chunk boundary."""
+    rng = np.random.default_rng(msz + nvar)
+    model = _dense_model(msz, nvar, 7, density=1.0)
+    if mixed:                    # a few sparse constraints behind the dense ones
+        A = [list(model.A[0])]
+        for _ in range(6):
+            i, j = rng.integers(0, msz, 2)
+            M = sp.lil_matrix((msz, msz)); M[i, j] = M[j, i] = rng.standard_normal(); M[i, i] = 1.0
+            A[0].append(sp.csc_matrix(M))
+        model = lo.make_model(A, rng.standard_normal(len(A[0]) - 1), 0.0, None, None)
+    n = model.n
+    W, G = _spd(msz, 9)
+    dev.set_option("dense_threshold", 1000)
+    try:
+        _upload(dev, model)
+        dev.set_scaling(0, W, G)
+        AAd = model.AA[0].toarray()
+        # makeRHS with a non-symmetric Rd + S: h = Rp + AA vec(W (Rd+S) W)
+        RdS = rng.standard_normal((msz, msz))
+        Rp = rng.standard_normal(n)
+        h = dev.make_rhs(Rp, [RdS])
+        ref = Rp + AAd @ (W @ RdS @ W).reshape(-1, order="F")
+        assert relerr(h, ref) < 1e-12
+        # MyA through the dense route: mat(AA'x), two products, AA vec(.)
+        dev.set_option("matvec_h", 1)
+        x = rng.standard_normal(n)
+        Mx = (AAd.T @ x).reshape(msz, msz, order="F"); Mx = 0.5 * (Mx + Mx.T)
+        assert relerr(dev.matvec(x), AAd @ (W @ Mx @ W).reshape(-1, order="F")) < 1e-12
+    finally:
+        dev.set_option("dense_threshold", -1)
+        dev.set_option("matvec_h", 0)
