@@ -155,6 +155,7 @@ struct lrn_ctx {
   bool hop_use = false;
   long cg_cur_iters = 0, cg_prev_iters = 0;
   lrn::DBuf hopbuf;           // partial sums of the triangular mat-vec
+  bool lz_no_persist = false; // a resident multi-step Lanczos launch timed out at a barrier once: per-step launches from then on
   double* pin = nullptr;      // host-mapped words the CG kernels write their exit code to (lrn_pcg), and their device address
   double* pin_dev = nullptr;
   lrn::DBuf cgpart;           // partial sums of the CG recurrence kernels

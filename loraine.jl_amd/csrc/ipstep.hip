@@ -215,11 +215,8 @@ __global__ __launch_bounds__(1024) void lz_step_kernel(const double* __restrict_
 // buffers so that nothing a workgroup still reads is overwritten inside a launch.  `do_symv` = 0: only finish step j-1
 // (last launch of a batch: the host needs alpha, beta of every step it reads).
 static constexpr int LZ_FUSED_MAX = 4096;
-__global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict__ M, int n, int nwg, int j, int do_symv, int qmod,
-                                                       double* __restrict__ Q3, double* __restrict__ Y2, double* __restrict__ PA2,
-                                                       double* __restrict__ ab) {
-  extern __shared__ double qs[];            // q_j (n doubles)
-  __shared__ double sh[16 * 16 + 8];
+__device__ __forceinline__ void lz_fused_body(const double* __restrict__ M, int n, int nwg, int j, int do_symv, int qmod,
+                                              double* Q3, double* Y2, double* PA2, double* ab, double* qs, double* sh) {
   const int t = threadIdx.x;
   double* qj = Q3 + (size_t)(j % qmod) * n;       // qmod = 3: rotating buffers; > number of steps: every q_j is kept
   if (j == 0) {
@@ -284,6 +281,58 @@ __global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict_
     for (int off = 8; off > 0; off >>= 1) d += __shfl_down(d, off, 16);
     if (t == 0) PA2[(size_t)(j & 1) * nwg + blockIdx.x] = d;
   }
+}
+
+__global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict__ M, int n, int nwg, int j, int do_symv, int qmod,
+                                                       double* Q3, double* Y2, double* PA2, double* ab) {
+  extern __shared__ double qs[];            // q_j (n doubles)
+  __shared__ double sh[16 * 16 + 8];
+  lz_fused_body(M, n, nwg, j, do_symv, qmod, Q3, Y2, PA2, ab, qs, sh);
+}
+
+// ---- the same steps [j0, j1) in ONE launch (round 4): a batch of Lanczos steps is a chain of launches of 7-8 us each
+// for 2-3 us of work (3200-3700 of them per C2 / C3 solve, 16-21 % of the GPU time).  Here the nwg <= 256 workgroups stay
+// resident and meet at a barrier after every step: a monotonic counter in global memory (release fence, one atomic add per
+// workgroup, acquire fence; every workgroup executes the same number of barriers).  The kernel can NOT hang: a workgroup
+// that waits longer than `limit` ticks of the 100 MHz wall clock (its peers were not scheduled -- a GPU shared with another
+// process, an over-subscribed chip) raises flag[1], every workgroup leaves at its next barrier, and the host redoes the run
+// with one launch per step (lz_collect).  flag[0]: the counter, flag[1]: abort.
+__device__ __forceinline__ bool lz_grid_barrier(unsigned* flag, unsigned target, long long limit, int* ok_s) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(flag, 1u);
+    int ok = 1;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (wall_clock64() - t0 > limit) {
+        __hip_atomic_store(flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();
+    *ok_s = ok;
+  }
+  __syncthreads();
+  return *ok_s != 0;
+}
+
+__global__ __launch_bounds__(256) void lz_fused_multi_kernel(const double* __restrict__ M, int n, int nwg, int j0, int j1,
+                                                             int qmod, double* Q3, double* Y2, double* PA2, double* ab,
+                                                             unsigned* flag, unsigned base, long long limit) {
+  extern __shared__ double qs[];
+  __shared__ double sh[16 * 16 + 8];
+  __shared__ int ok_s;
+  unsigned target = base;
+  for (int j = j0; j < j1; ++j) {
+    lz_fused_body(M, n, nwg, j, 1, qmod, Q3, Y2, PA2, ab, qs, sh);
+    target += (unsigned)nwg;
+    if (!lz_grid_barrier(flag, target, limit, &ok_s)) return;
+  }
+  if (blockIdx.x == 0) lz_fused_body(M, n, nwg, j1, 0, qmod, Q3, Y2, PA2, ab, qs, sh);      // finish step j1 - 1
 }
 
 // steps [j0, j1) of the single-launch Lanczos recurrence with every q_j kept (Q: (j1 + 1) x n doubles, q_0 = unit start
@@ -400,6 +449,9 @@ struct LzRun {
   bool have_prev = false, conv = false, done = false;
   bool fused = false;                       // lz_fused_kernel: Q3 = q (3 n), Y2 = w (2 n), PA2 = ypart (2 nwg)
   int nwg = 0;
+  bool persist = false;                     // lz_fused_multi_kernel: a batch of steps per launch
+  unsigned* flag = nullptr;                 // its barrier counter and abort word
+  unsigned bar_base = 0;                    // barriers passed so far x nwg
 };
 
 static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st, DBuf& buf) {
@@ -419,11 +471,17 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   r.w = r.q + 3 * (size_t)n;              // fused: Y2 = w[0..2n)
   r.ypart = r.w + 2 * (size_t)n;          // fused: PA2
   r.ab = r.ypart + (size_t)std::max(r.nchunk * n, 2 * r.nwg);
+  static const bool no_persist = getenv("LRN_LZ_PERSIST") && atoi(getenv("LRN_LZ_PERSIST")) == 0;
+  r.persist = r.fused && !no_persist && !c->lz_no_persist && r.nwg <= 256;
+  r.flag = reinterpret_cast<unsigned*>(r.ab + 2 * (size_t)r.mmax + 8);      // (inside the 64 doubles of slack)
+  r.bar_base = 0;
   return LRN_OK;
 }
 
 // start vector (after lz_begin; a fresh workspace is zeroed on c->stream, which r.st must have waited for)
 static void lz_start(LzRun& r) {
+  if (r.persist) (void)hipMemsetAsync(r.flag, 0, 16, r.st);
+  r.bar_base = 0;
   hipLaunchKernelGGL(lz_init_kernel, dim3((r.n + 255) / 256), dim3(256), 0, r.st, r.q, r.n);
   hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, r.st, r.ypart, r.nchunk, r.n, -1, r.q, r.qprev, r.w, r.ab);
 }
@@ -431,6 +489,12 @@ static void lz_start(LzRun& r) {
 static void lz_launch(LzRun& r) {
   const int batch = r.n <= 16 ? r.n : 16;
   r.m1 = std::min(r.mmax, r.m + batch);
+  if (r.fused && r.persist) {
+    hipLaunchKernelGGL(lz_fused_multi_kernel, dim3(r.nwg), dim3(256), (size_t)r.n * 8, r.st, r.M, r.n, r.nwg, r.m, r.m1, 3, r.q,
+                       r.w, r.ypart, r.ab, r.flag, r.bar_base, 2000000LL);          // limit: 20 ms at 100 MHz
+    r.bar_base += (unsigned)(r.m1 - r.m) * (unsigned)r.nwg;
+    return;
+  }
   if (r.fused) {
     const size_t lds = (size_t)r.n * 8;
     for (int j = r.m; j < r.m1; ++j)
@@ -449,7 +513,20 @@ static int lz_collect(lrn_ctx* c, LzRun& r) {
   const int m1 = r.m1;
   r.hab.resize(2 * (size_t)m1);
   LRN_HIP(c, hipMemcpyAsync(r.hab.data(), r.ab, (size_t)2 * m1 * 8, hipMemcpyDeviceToHost, r.st));
+  unsigned fl[2] = {0u, 0u};
+  if (r.persist) LRN_HIP(c, hipMemcpyAsync(fl, r.flag, 8, hipMemcpyDeviceToHost, r.st));
   LRN_HIP(c, hipStreamSynchronize(r.st));
+  if (r.persist && fl[1] != 0u) {
+    // the resident workgroups did not all meet in time (see lz_fused_multi_kernel): from now on one launch per step on
+    // this context, and this run again from its start vector
+    c->lz_no_persist = true;
+    c->counts["lz_persist_abort"] += 1;
+    r.persist = false;
+    r.m = 0; r.have_prev = false; r.scale = 0.0;
+    lz_start(r);
+    lz_launch(r);
+    return lz_collect(c, r);
+  }
   r.a.resize(m1); r.b.resize(m1);
   int mm_ = m1;
   for (int j = 0; j < m1; ++j) {
@@ -952,8 +1029,8 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
       // everything in the L_X basis (prepw.hip::prepare_w_ns): Bs = L_X' dS L_X, T = Z Bs Z / c,
       // TX = L_X^-1 dX L_X^-T = -I - T (+ sigma_mu K^-1 + R), dX = L_X TX L_X'                  (:253-257)
       const unsigned gs = (unsigned)std::min<long>(1024, ((long)(m + 31) / 32) * ((m + 31) / 32));
-      LRN_TRY(pgemm_nt(c, c->stream, m, b.LXt.as<double>(), b.delS.as<double>(), t0));
-      LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.LXt.as<double>(), t1));
+      LRN_TRY(pgemm_nt(c, c->stream, m, b.LXt.as<double>(), b.delS.as<double>(), t0, GEMM_KFROM_M));    // L_X' upper triangular
+      LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.LXt.as<double>(), t1, GEMM_KFROM_N));
       hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, b.Bs.as<double>(), (const double*)nullptr,
                          (double*)nullptr);
       LRN_TRY(pgemm_nt(c, c->stream, m, b.Zh.as<double>(), b.Bs.as<double>(), t0));
@@ -961,8 +1038,8 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
       hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, t3, (const double*)nullptr, (double*)nullptr);
       hipLaunchKernelGGL(tx_kernel, dim3(g), dim3(256), 0, c->stream, t3, sigma_mu / b.ns_c, b.Ki.as<double>(),
                          predict ? (const double*)nullptr : b.RNT.as<double>(), b.TX.as<double>(), m);
-      LRN_TRY(pgemm_nt(c, c->stream, m, b.LXf.as<double>(), b.TX.as<double>(), t0));
-      LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXf.as<double>(), b.delX.as<double>(), 1.0));
+      LRN_TRY(pgemm_nt(c, c->stream, m, b.LXf.as<double>(), b.TX.as<double>(), t0, GEMM_KTO_M));        // L_X lower triangular
+      LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXf.as<double>(), b.delX.as<double>(), 1.0, GEMM_KTO_N));
       // the scaled directions of the step-length rule are orthogonally similar to TX and T               (:263-285)
       LRN_TRY(eigmin_certified_pair(c, b.TX.as<double>(), t3, m, &lamX, &lamS));
       alpha[il] = lamX > -1e-6 ? 0.99 : std::min(1.0, -tau / lamX);
@@ -1036,8 +1113,8 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
         c->counts["lyap_steps"] += steps;
         c->counts["lyap_solves"] += 1;
         if (ok) {
-          LRN_TRY(pgemm_nt(c, c->stream, m, b.LXf.as<double>(), b.RNT.as<double>(), t0));
-          LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXf.as<double>(), b.Qm.as<double>(), 1.0));
+          LRN_TRY(pgemm_nt(c, c->stream, m, b.LXf.as<double>(), b.RNT.as<double>(), t0, GEMM_KTO_M));
+          LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXf.as<double>(), b.Qm.as<double>(), 1.0, GEMM_KTO_N));
           toc(c, "lyap");
           continue;
         }

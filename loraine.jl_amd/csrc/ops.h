@@ -18,14 +18,16 @@ int nt_factor(lrn_ctx* c, LmiBlock& b, int* info, double* minpiv);
 int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags = 0, double alpha = 1.0,
             double* Ct = nullptr);     // Ct: the transposed result as well
 // the same for a product that is symmetric in exact arithmetic; C comes back exactly symmetric
-int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha = 1.0);
+int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha = 1.0, int tri = 0);
 // The same products for the resident path of a sharded run (one process per GPU): when the communicator has more than one
 // rank, `st` is the context's stream and n >= option shard_products_min, this rank computes its block of columns and the
 // blocks are all-gathered in place (csrc/comm.hip) -- every rank ends with the same bits; otherwise the plain product.
 bool products_sharded(const lrn_ctx* c, hipStream_t st, int n);
-int pgemm_nt(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags = 0,
+// tri: GEMM_KFROM_M / GEMM_KFROM_N / GEMM_KTO_M / GEMM_KTO_N when op(A) / op(B) is triangular with stored zeros (prepw.hip)
+int pgemm_nt(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, int tri = 0,
              double alpha = 1.0, double* Ct = nullptr);
-int pgemm_nt_sym(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha = 1.0);
+int pgemm_nt_sym(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha = 1.0,
+                 int tri = 0);
 // k largest eigenpairs (ascending), smallest eigenvalue and trace of a dense symmetric matrix
 int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
                      double* trace, int* steps_out);

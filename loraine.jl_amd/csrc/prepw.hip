@@ -358,9 +358,9 @@ __global__ __launch_bounds__(256) void mirror_diag_tiles_kernel(double* __restri
   }
 }
 
-int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha) {
+int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha, int tri) {
   if (n >= 1500) {
-    LRN_TRY(gemm_nt(st, n, A, Bm, C, GEMM_TRI_LOWER | GEMM_C_MIRROR, alpha));
+    LRN_TRY(gemm_nt(st, n, A, Bm, C, GEMM_TRI_LOWER | GEMM_C_MIRROR | ((n & 1) ? 0 : tri), alpha));
     hipLaunchKernelGGL(mirror_diag_tiles_kernel, dim3((n + 127) / 128), dim3(256), 0, st, C, n);
     return LRN_OK;
   }
@@ -380,9 +380,15 @@ static int shard_cols(const lrn_ctx* c, int n, int* c0, int* c1) {
   return cb;
 }
 
-int pgemm_nt(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags, double alpha,
+// `tri`: which operand is triangular with explicit zeros in its other triangle (GEMM_KFROM_M / _N: zero for k < m / k < n,
+// GEMM_KTO_M / _N: zero for k > m / k > n; one flag) -- the K loop of every tile then covers only the range where that
+// operand is not zero: half the work of the products with L_X, L_X', L_S^-T (bitwise the same sums: the skipped terms
+// are exact zeros).  Taken where the 128-tile kernel runs (n >= 1500, even); the sharded product ignores it.
+static inline int tri_hint(int n, int tri) { return (n >= 1500 && (n & 1) == 0) ? tri : 0; }
+
+int pgemm_nt(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, int tri, double alpha,
              double* Ct) {
-  if (flags != 0 || !products_sharded(c, st, n)) return gemm_nt(st, n, A, Bm, C, flags, alpha, Ct);
+  if (!products_sharded(c, st, n)) return gemm_nt(st, n, A, Bm, C, tri_hint(n, tri), alpha, Ct);
   int c0, c1;
   const int cb = shard_cols(c, n, &c0, &c1);
   if (c1 > c0) {
@@ -400,8 +406,8 @@ int pgemm_nt(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* B
   return LRN_OK;
 }
 
-int pgemm_nt_sym(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha) {
-  if (!products_sharded(c, st, n)) return gemm_nt_sym(st, n, A, Bm, C, alpha);
+int pgemm_nt_sym(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha, int tri) {
+  if (!products_sharded(c, st, n)) return gemm_nt_sym(st, n, A, Bm, C, alpha, tri);
   LRN_TRY(pgemm_nt(c, st, n, A, Bm, C, 0, alpha, nullptr));
   hipLaunchKernelGGL(sym_inplace_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, C, n);
   return LRN_OK;
@@ -541,7 +547,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   } else
   LRN_TRY(trsm_left_lower(s2, LS, n, n, nullptr, false, LSi, n, n, tw2));
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LSi, n, LSit);   // L_S^-T
-  LRN_TRY(pgemm_nt_sym(c, s2, n, LSit, LSit, b.Si.as<double>(), 1.0));
+  LRN_TRY(pgemm_nt_sym(c, s2, n, LSit, LSit, b.Si.as<double>(), 1.0, GEMM_KFROM_M));          // L_S^-T upper triangular
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, LX, n, LXt);
   // K = CC' CC with CC = L_S' L_X (prepare_W.jl:39) -- NOT L_X' S L_X: with cond(X), cond(S) at 1e10 the entries of
   // |L_X'| |S| |L_X| are 1e10 times those of K and the explicit product has no correct digit left (measured: the
@@ -549,7 +555,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   double* Y = b.Yh.as<double>();
   double* Z = b.Zh.as<double>();
   if (two) LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
-  LRN_TRY(pgemm_nt(c, st, n, LXt, LSt, Pm, 0, 1.0));                                      // CC' = L_X' L_S
+  LRN_TRY(pgemm_nt(c, st, n, LXt, LSt, Pm, GEMM_KFROM_M, 1.0));                           // CC' = L_X' L_S (L_X' upper)
   LRN_TRY(pgemm_nt_sym(c, st, n, Pm, Pm, Tm, 1.0));                                        // K = CC' CC
   hipLaunchKernelGGL(colnorm_kernel, dim3(n), dim3(256), 0, st, Tm, n, colsum, colsq);
   hipLaunchKernelGGL(normc_kernel, dim3(1), dim3(256), 0, st, colsum, colsq, n, sc);
@@ -575,7 +581,8 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   // Y T and T Z are independent: the second one on a third stream, so that two workgroups share every CU where one
   // product alone (256 tiles of 128 at msz 2000) leaves each CU a single workgroup
   hipStream_t s3 = st;
-  if (c->opt.prepw_streams && n >= 1024 && !shp) {
+  static const int s3_min = getenv("LRN_NS_S3_MIN") ? atoi(getenv("LRN_NS_S3_MIN")) : 1024;      // (measurement knob)
+  if (c->opt.prepw_streams && n >= s3_min && !shp) {
     if (!c->stream3) {
       LRN_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
       LRN_HIP(c, hipEventCreateWithFlags(&c->evC, hipEventDisableTiming));
@@ -649,8 +656,8 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   if (Yc != Y) LRN_HIP(c, hipMemcpyAsync(Y, Yc, mm, hipMemcpyDeviceToDevice, st));
   if (Zc != Z) LRN_HIP(c, hipMemcpyAsync(Z, Zc, mm, hipMemcpyDeviceToDevice, st));
   // W = L_X K^-1/2 L_X' = L_X Z L_X' / sqrt(c)                                          (prepare_W.jl:64)
-  LRN_TRY(pgemm_nt(c, st, n, LX, Ztc, Pm, 0, 1.0));
-  LRN_TRY(pgemm_nt_sym(c, st, n, Pm, LX, b.W.as<double>(), 1.0 / std::sqrt(b.ns_c)));
+  LRN_TRY(pgemm_nt(c, st, n, LX, Ztc, Pm, GEMM_KTO_M, 1.0));                             // (L_X lower triangular)
+  LRN_TRY(pgemm_nt_sym(c, st, n, Pm, LX, b.W.as<double>(), 1.0 / std::sqrt(b.ns_c), GEMM_KTO_N));
   // (K/c)^-1 = Zh^2: the sigma_mu S^-1 term of the corrector in the L_X basis
   LRN_TRY(pgemm_nt(c, st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
   if (two) {                                                  // join: Si is complete when this returns

@@ -73,6 +73,28 @@ def _worker(rank, world, port, out_dir):
     out["dense"] = dict(status=solver.status, iters=solver.iter, obj=float(solver.primal_obj),
                         schur_chol=dev.count("schur_chol"), plan=dev.count("schur_plan_agreed"))
     dev.comm_destroy()
+    # a rank that cannot allocate its exchange buffers must take its peers down with it, not leave them in the
+    # collective.  Rank 1's next exchange fails its allocation (test hook "comm_fail_ensure"): BOTH ranks must come back
+    # from lrn_schur_assemble with an error (rank 0 would sit in the all-gather for ever otherwise), and the next
+    # assembly works again.
+    model = model_from_sdpa(os.path.join(GOLD, "theta1.dat-s"))
+    solver, ha = resident.load(model, dict(kit=0, verb=0), device=dev)
+    hot = DistributedHotPath(solver, rank, world)
+    dev.set_scaling(0, np.eye(int(model.msizes[0])))
+    if rank == 1:
+        dev.set_option("comm_fail_ensure", 1)
+    try:
+        dev.schur_assemble(0)
+        out["inject"] = dict(raised=False, msg="")
+    except loraine_jl_amd.LoraineHipError as e:
+        out["inject"] = dict(raised=True, msg=str(e))
+    try:
+        dev.schur_assemble(0)
+        out["inject"]["second_ok"] = dev.schur_factor() == 0
+    except loraine_jl_amd.LoraineHipError as e:
+        out["inject"]["second_ok"] = False
+        out["inject"]["msg2"] = str(e)
+    dev.comm_destroy()
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump(out, f)
     dist.barrier()
@@ -101,6 +123,9 @@ def test_two_ranks_on_one_gpu_solve_through_the_library_communicator(tmp_path):
     assert r[0]["theta1_products"]["iters"] == r[0]["theta1"]["iters"]
     assert r[0]["dense"]["status"] == 1 and r[0]["dense"]["obj"] == r[1]["dense"]["obj"]
     assert r[0]["dense"]["iters"] == r[1]["dense"]["iters"]
+    assert r[0]["inject"]["raised"] and r[1]["inject"]["raised"]            # nobody was left in the collective
+    assert "another rank" in r[0]["inject"]["msg"] and "injected" in r[1]["inject"]["msg"]
+    assert r[0]["inject"]["second_ok"] and r[1]["inject"]["second_ok"]
     # the same dense problem on ONE rank (here, in the parent): the two-rank run -- column split of the assembly, the passes
     # over the constraint data split by constraints, both summed by all-reduces -- must land on the same iterates
     import loraine_jl_amd

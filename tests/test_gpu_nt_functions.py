@@ -181,6 +181,30 @@ def test_one_iteration_function_by_function_on_ill_conditioned_iterates(dev, con
     _check(e, tol, max(1e-9, 4 * tol), f"cond={cond:g} nt_mode={nt_mode}")
 
 
+@pytest.mark.parametrize("nt_mode", [1, 0])
+def test_one_iteration_function_by_function_at_the_size_of_the_128_tile_kernels(dev, nt_mode):
+    """msz 1536: from 1500 on the products with the Cholesky factors (L_X' dS L_X, L_X TX L_X', L_X Z L_X', L_S^-T L_S^-1)
+    run on the 128-tile kernel over the triangular K ranges only (csrc/prepw.hip::pgemm_nt, round 4), and P = Z Y of the
+    Newton-Schulz iteration as lower tiles + mirror."""
+    m, nvar = 1536, 6
+    rng = np.random.default_rng(2)
+    A = [sp.csc_matrix((m, m))]
+    for _ in range(nvar):
+        M = sp.random(m, m, density=0.002, random_state=rng, data_rvs=rng.standard_normal)
+        A.append(sp.csc_matrix((M + M.T) / 2))
+    C0 = sp.random(m, m, density=0.01, random_state=rng, data_rvs=rng.standard_normal)
+    A[0] = sp.csc_matrix(-(C0 + C0.T) / 2)
+    model = lo.make_model([A], rng.standard_normal(nvar), 0.0, None, None)
+    X, S = _near_central_path(m, 1e6, 4)
+    y = 0.1 * rng.standard_normal(nvar)
+    st = _oracle_step(model, X, S, y, dict(kit=0))
+    try:
+        e = _device_step(dev, model, X, S, y, st, nt_mode)
+    finally:
+        dev.set_option("nt_mode", 1)
+    _check(e, 2e-10, 2e-9, f"msz 1536 nt_mode={nt_mode}")
+
+
 def _run(path, device, **opts):
     from loraine_jl_amd.optimizer import Optimizer
     o = Optimizer(resident=True, device=device)
