@@ -37,6 +37,11 @@ struct Prec {
   // SMW core as an explicit inverse (option prec_inv): Sm = S + I, Ainv = (S + I)^-1 = L^-T L^-1
   bool has_inv = false;
   DBuf Sm, Ainv;
+  // the whole preconditioner as one dense symmetric matrix (lower triangle), round 4:
+  //   M^-1 = D^-1/2 (I - ts (S + I)^-1 ts') D^-1/2
+  // -- inside lrn_pcg the seven launches of the SMW apply become one pass over nvar (nvar + 1) / 2 doubles (symv_lower)
+  bool has_dense = false;
+  DBuf Minv, T1;
 };
 
 // y = alpha M x + beta z for a symmetric n x n matrix, 16 rows per workgroup, x staged in LDS (n <= 8192): one launch
@@ -101,7 +106,7 @@ void prec_free(lrn_ctx* c) {
   if (!c->prec) return;
   Prec* p = c->prec;
   for (DBuf* d : {&p->d, &p->ts, &p->cholS, &p->linvS, &p->cw, &p->y, &p->y2, &p->y3, &p->y4, &p->zpart, &p->E, &p->Um,
-                  &p->AU, &p->sig, &p->LD, &p->linvD, &p->wD, &p->Cd, &p->Sm, &p->Ainv})
+                  &p->AU, &p->sig, &p->LD, &p->linvD, &p->wD, &p->Cd, &p->Sm, &p->Ainv, &p->Minv, &p->T1})
     release(*d);
   delete p;
   c->prec = nullptr;
@@ -1385,6 +1390,7 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
   Prec* P = c->prec;
   P->kind = kind;
   P->erank = erank;
+  P->has_dense = false;
   const int n = c->nvar;
   hipStream_t st = c->stream;
   if (kind == 0) return LRN_OK;
@@ -1615,6 +1621,60 @@ int prec_setup(lrn_ctx* c, int kind, int erank, int aamat, int* info) {
   return LRN_OK;
 }
 
+// Minv[i,j] = (delta_ij - G[i,j]) / sqrt(d_i d_j) on the lower triangle (G = T1 ts', lower tiles)
+__global__ void minv_finish_kernel(double* __restrict__ Mi, int n, const double* __restrict__ d) {
+  const long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(e % n), j = (int)(e / n);
+    if (i >= j) Mi[e] = ((i == j ? 1.0 : 0.0) - Mi[e]) / sqrt(d[i] * d[j]);
+  }
+}
+
+// H_alpha as a dense matrix: is it worth forming for `expected` applications?  (static model, as hop_worthwhile)
+static bool prec_dense_worthwhile(const lrn_ctx* c, const Prec* P, long expected) {
+  if (!P || P->kind != 1 || P->has_LD || !P->has_inv || c->opt.prec_dense == 1) return false;
+  const double n = c->nvar, k = P->ksz;
+  if (c->nvar > 8192 || c->nvar < 256) return false;
+  if (c->opt.prec_dense == 2) return true;
+  const double setup = (6.0 * n * k * k + n * n * k) / 3.5e13 + 80e-6;      // T1 with one refinement step, T1 ts' (lower tiles)
+  const double per_apply = 45e-6;                                            // seven launches -> two
+  return (double)expected * per_apply > 1.2 * setup;
+}
+
+// T1 = ts (S + I)^-1 with one step of refinement (the accuracy of the SMW apply, which refines too), Minv from it
+static int prec_dense_build(lrn_ctx* c, Prec* P) {
+  const int n = c->nvar, ksz = P->ksz;
+  hipStream_t st = c->stream;
+  LRN_TRY(ensure(c, P->Minv, (size_t)n * n * 8));
+  LRN_TRY(ensure(c, P->T1, (size_t)2 * n * ksz * 8));
+  double* T1 = P->T1.as<double>();
+  double* R = T1 + (size_t)n * ksz;
+  auto mm = [&](const double* A, const double* B, double* C, double alpha, double beta) -> int {   // C = alpha A B + beta C, (n x ksz)(ksz x ksz), B symmetric
+    GemmDesc g;
+    g.A = A; g.sAm = 1; g.sAk = n;
+    g.B = B; g.sBk = 1; g.sBn = ksz;
+    g.C = C; g.sCm = 1; g.sCn = n;
+    g.M = n; g.N = ksz; g.K = ksz;
+    g.alpha = alpha; g.beta = beta;
+    return gemm(st, g);
+  };
+  LRN_TRY(mm(P->ts.as<double>(), P->Ainv.as<double>(), T1, 1.0, 0.0));
+  LRN_HIP(c, hipMemcpyAsync(R, P->ts.p, (size_t)n * ksz * 8, hipMemcpyDeviceToDevice, st));
+  LRN_TRY(mm(T1, P->Sm.as<double>(), R, -1.0, 1.0));                        // R = ts - T1 (S + I)
+  LRN_TRY(mm(R, P->Ainv.as<double>(), T1, 1.0, 1.0));                       // T1 += R (S + I)^-1
+  GemmDesc g;                                                               // G = T1 ts' (lower tiles)
+  g.A = T1; g.sAm = 1; g.sAk = n;
+  g.B = P->ts.as<double>(); g.sBk = n; g.sBn = 1;
+  g.C = P->Minv.as<double>(); g.sCm = 1; g.sCn = n;
+  g.M = g.N = n; g.K = ksz;
+  g.flags = GEMM_TRI_LOWER;
+  LRN_TRY(gemm(st, g));
+  hipLaunchKernelGGL(minv_finish_kernel, dim3(nb((long)n * n)), dim3(256), 0, st, P->Minv.as<double>(), n, P->d.as<double>());
+  P->has_dense = true;
+  c->counts["prec_dense_build"] += 1;
+  return LRN_OK;
+}
+
 // Mx = M^-1 x, device vectors; tmpv: nvar scratch
 int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
   Prec* P = c->prec;
@@ -1627,6 +1687,10 @@ int prec_apply_dev(lrn_ctx* c, const double* x, double* Mx, double* tmpv) {
   if (P->kind == 2) {                                        // MyM_beta (Solvers.jl:670-672)
     hipLaunchKernelGGL(div_kernel, dim3(nb(n)), dim3(256), 0, st, x, P->d.as<double>(), Mx, n, 0);
     return LRN_OK;
+  }
+  if (P->has_dense) {                                        // (lrn_pcg when the cost model formed it; option prec_dense = 2)
+    c->counts["prec_dense_apply"] += 1;
+    return symv_lower(c, P->Minv.as<double>(), n, nullptr, x, Mx);
   }
   const int ksz = P->ksz;                                    // MyM (Solvers.jl:866-904), ts form
   if (P->has_LD) {      // v = L_D^-1 x  (d holds ones)
@@ -1752,6 +1816,7 @@ int pcg_dev(lrn_ctx* c, const double* b, double tol, int maxit, double* x, int* 
   for (int i = 0; i < NSLOT * 16; ++i) hs[i] = 0.0;
   bool use_h = false;
   LRN_TRY(op_select(c, &use_h));
+  if (c->prec && !c->prec->has_dense && prec_dense_worthwhile(c, c->prec, c->cg_prev_iters)) LRN_TRY(prec_dense_build(c, c->prec));
   const int kind = (c->prec && (c->prec->kind == 1 || c->prec->kind == 2)) ? c->prec->kind : 0;
   const double* dprec = kind == 2 ? c->prec->d.as<double>() : nullptr;
   LRN_TRY(prec_apply_dev(c, r, z, tmpv));
@@ -1846,6 +1911,8 @@ extern "C" int lrn_prec_apply(lrn_ctx* c, const double* x, double* Mx) {
   LRN_HIP(c, hipSetDevice(c->device));
   const int n = c->nvar;
   LRN_TRY(copy_in(c, c->v0.p, x, (size_t)n * 8));
+  if (c->prec && !c->prec->has_dense && c->opt.prec_dense == 2 && prec_dense_worthwhile(c, c->prec, 0))
+    LRN_TRY(prec_dense_build(c, c->prec));
   LRN_TRY(prec_apply_dev(c, c->v0.as<double>(), c->v1.as<double>(), c->v2.as<double>()));
   return copy_out(c, Mx, c->v1.p, (size_t)n * 8);
 }

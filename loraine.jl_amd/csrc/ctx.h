@@ -110,6 +110,8 @@ struct LrnOptions {
   int shard_products = 1;         // multi-GPU: the n^3 products of the resident path (Newton-Schulz, Lyapunov CG, step) by
   int shard_products_min = 4096;  // column blocks + all-gather from this matrix side on (one product of 10^4: 31 ms; below, the
                                   // all-gather costs more than the product)
+  int prec_dense = 0;             // H_alpha inside lrn_pcg as ONE dense symmetric matrix M^-1 (nvar <= 8192): 0 auto (cost model), 1 never, 2 always
+                                  // (also in lrn_prec_apply)
   int matvec_h = 0;               // CG operator through the assembled Schur matrix (hop.hip): 0 auto (cost model), 1 never
                                   // (the matrix-free MyA always), 2 always
   int pcg_lookahead = 2;          // lrn_pcg: iterations the host queues beyond the one whose convergence test it has read
@@ -217,6 +219,8 @@ int schur_get(lrn_ctx* c, double* Hout);
 // hop.hip: the CG operator through the assembled matrix
 // y = H x; qpart (may be null): receives *nq partial sums of x'y (*nq = 0: not formed, e.g. sharded)
 int hop_apply(lrn_ctx* c, const double* x_dev, double* y_dev, double* qpart = nullptr, int* nq = nullptr);
+int symv_lower(lrn_ctx* c, const double* A_dev, int n, const int* idx, const double* x_dev, double* y_dev,
+               double* qpart = nullptr, int* nq = nullptr, bool sharded = false);
 bool hop_worthwhile(lrn_ctx* c, long expected_iters);
 int hop_prepare(lrn_ctx* c);
 }  // namespace lrn

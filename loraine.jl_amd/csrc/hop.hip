@@ -194,20 +194,17 @@ static bool hop_shardable(const lrn_ctx* c) {
 
 // y = H x (natural constraint order on both sides; H lives in sigma-position space when nlmi == 1).  world > 1: this
 // rank's column chunks only, the caller all-reduces.
-int hop_apply(lrn_ctx* c, const double* x, double* y, double* qpart, int* nq) {
-  const int n = c->nvar;
-  if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+// y = A x for a symmetric n x n matrix of which the lower triangle is read (idx: permutation of both sides or null)
+int symv_lower(lrn_ctx* c, const double* H, int n, const int* idx, const double* x, double* y, double* qpart, int* nq,
+               bool sharded) {
   const bool small = n < 8192;
   const int K = small ? 1 : 4, RB = 128 * K;
   const int nrb = (n + RB - 1) / RB, nch = (n + 127) / 128;
   LRN_TRY(ensure(c, c->hopbuf, (size_t)(nrb + nch) * n * 8));
   double* colpart = c->hopbuf.as<double>();
   double* rowpart = colpart + (size_t)nrb * n;
-  const int* idx = c->pos_space ? c->lmi[0].sigma_d.as<int>() : nullptr;
-  const bool sharded = c->comm && c->world > 1;
   const int rank = sharded ? c->rank : 0, world = sharded ? c->world : 1;
   const dim3 grid(nch, nrb);
-  const double* H = c->H.as<double>();
   const bool vec2 = (n & 1) == 0;
 #define LRN_SYMV(KK, VV)                                                                                               \
   hipLaunchKernelGGL((symv_lower_tiles_kernel<KK, VV>), grid, dim3(256), 0, c->stream, H, n, idx, x, colpart, rowpart, \
@@ -220,8 +217,14 @@ int hop_apply(lrn_ctx* c, const double* x, double* y, double* qpart, int* nq) {
   hipLaunchKernelGGL(symv_lower_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, c->stream, colpart, rowpart, n, RB,
                      idx, x, y, qp, rank, world, c->shard_bs);
   if (nq) *nq = qp ? (n + 63) / 64 : 0;
-  c->counts["hop_matvec"] += 1;
   return LRN_OK;
+}
+
+int hop_apply(lrn_ctx* c, const double* x, double* y, double* qpart, int* nq) {
+  if (!c->have_H) return set_error(c, LRN_ERR_STATE, "no assembled H");
+  c->counts["hop_matvec"] += 1;
+  return symv_lower(c, c->H.as<double>(), c->nvar, c->pos_space ? c->lmi[0].sigma_d.as<int>() : nullptr, x, y, qpart, nq,
+                    c->comm && c->world > 1);
 }
 
 // ------------------------------------------------------------------ cost model (static: the choice must not depend on

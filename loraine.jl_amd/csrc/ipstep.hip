@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict_
   lz_fused_body(M, n, nwg, j, do_symv, qmod, Q3, Y2, PA2, ab, qs, sh);
 }
 
-// ---- the same steps [j0, j1) in ONE launch (round 4): a batch of Lanczos steps is a chain of launches of 7-8 us each
-// for 2-3 us of work (3200-3700 of them per C2 / C3 solve, 16-21 % of the GPU time).  Here the nwg <= 256 workgroups stay
+// ---- the same steps [j0, j1) in ONE launch (round 4; MEASURED SLOWER, kept behind LRN_LZ_PERSIST=1 for the record): a batch
+// of Lanczos steps is a chain of launches of 7-8 us each for 2-3 us of work.  Here the nwg <= 256 workgroups stay
 // resident and meet at a barrier after every step: a monotonic counter in global memory (release fence, one atomic add per
 // workgroup, acquire fence; every workgroup executes the same number of barriers).  The kernel can NOT hang: a workgroup
 // that waits longer than `limit` ticks of the 100 MHz wall clock (its peers were not scheduled -- a GPU shared with another
@@ -471,8 +471,10 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   r.w = r.q + 3 * (size_t)n;              // fused: Y2 = w[0..2n)
   r.ypart = r.w + 2 * (size_t)n;          // fused: PA2
   r.ab = r.ypart + (size_t)std::max(r.nchunk * n, 2 * r.nwg);
-  static const bool no_persist = getenv("LRN_LZ_PERSIST") && atoi(getenv("LRN_LZ_PERSIST")) == 0;
-  r.persist = r.fused && !no_persist && !c->lz_no_persist && r.nwg <= 256;
+  // (measurement knob, off: with two runs interleaved on two streams the per-step launches are hidden already and the
+  // barrier -- device-scope release / acquire across eight L2s -- costs more than a launch: maxG11 find_step 1.0 -> 1.25 ms)
+  static const bool persist_on = getenv("LRN_LZ_PERSIST") && atoi(getenv("LRN_LZ_PERSIST")) != 0;
+  r.persist = r.fused && persist_on && !c->lz_no_persist && r.nwg <= 256;
   r.flag = reinterpret_cast<unsigned*>(r.ab + 2 * (size_t)r.mmax + 8);      // (inside the 64 doubles of slack)
   r.bar_base = 0;
   return LRN_OK;

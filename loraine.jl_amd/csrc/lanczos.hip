@@ -247,6 +247,8 @@ static int lanczos_extremes_plain(lrn_ctx* c, const double* M, int n, int k, dou
     const double mean = std::fabs(tr - (k == 1 ? th_top : 0.0)) / (double)(n - k);
     const double rmin = std::fabs(b[m - 1] * s_min[m - 1]);
     done = worst <= 1e-10 && rmin <= 1e-6 * std::max(std::fabs(th_min), mean);
+    static const bool lx_trace = getenv("LRN_LX_TRACE") != nullptr;
+    if (lx_trace) fprintf(stderr, "[lx plain n=%d] m %d top %.6e worst %.2e | min %.6e rmin %.2e mean %.3e\n", n, m, th_top, worst, th_min, rmin, mean);
     // out of steps with the wanted pair converged: what the full version does at ITS cap of 160 steps (lambda_min, which only
     // enters tau through (lambda_min + mean) / 2, is then as settled as 240 steps make it)
     if (!done && m >= mmax && worst <= 1e-6) done = true;

@@ -492,6 +492,8 @@ class MySolver:
                 svd_sweeps=d.count("svd_sweeps"), find_step_ms=d.timing("find_step"),
                 rhs_ms=d.timing("rhs"), residual_d_ms=d.timing("residual_d"), stats_ms=d.timing("stats"),
                 hop_assemble=d.count("hop_assemble"), hop_matvec=d.count("hop_matvec"),
+                prec_lanczos_steps=d.count("prec_lanczos_steps"), lanczos_plain=d.count("lanczos_plain"),
+                prec_dense_build=d.count("prec_dense_build"),
                 ns_steps=d.count("ns_steps"), lyap_steps=d.count("lyap_steps"), lyap_ms=d.timing("lyap"),
                 ns_fallback=d.count("ns_fallback"), lyap_fallback=d.count("lyap_fallback"),
                 lanczos_steps=d.count("lanczos_steps"), lanczos_runs=d.count("lanczos_runs"),

@@ -209,3 +209,45 @@ def test_solve_switches_to_H_by_the_cost_model_and_agrees(dev):
     assert out[0][2] > 0 and out[0][3] > 0          # (at this size the assembly pays only in the last iterations)
     assert abs(out[0][1] - out[1][1]) < 1e-6 * (1 + abs(out[1][1]))
     assert abs(out[0][1] - P.optimum) < 1e-5 * (1 + abs(P.optimum))
+
+
+def test_halpha_as_one_dense_matrix_equals_the_smw_apply(dev):
+    """H_alpha (MyM, reference src/Solvers.jl:866-904) formed once per scaling as the dense symmetric matrix
+    D^-1/2 (I - ts (S + I)^-1 ts') D^-1/2 and applied by one pass over its lower triangle (lrn_pcg takes it when the CG
+    iterations pay for the products; option prec_dense = 2 forces it): same M^-1 x as the SMW form, same cg exit codes,
+    iteration counts and solutions on the golden thetaG11 iterate -- alone and together with the operator through H."""
+    from loraine_jl_amd.model import model_from_sdpa
+    g = np.load(os.path.join(GOLD, "iterate_thetaG11.npz"))
+    model = model_from_sdpa(os.path.join(GOLD, "thetaG11.dat-s"), datarank=0)
+    m = int(model.msizes[0])
+
+    def unpack(lower_f32):
+        M = np.zeros((m, m))
+        M[np.tril_indices(m)] = lower_f32.astype(np.float64)
+        return M + np.tril(M, -1).T
+
+    X, S = unpack(g["X_lower_f32"]), unpack(g["S_lower_f32"])
+    dev.upload_model(model.AA, model.sigmaA, model.qA, model.msizes)
+    info, _ = dev.prepare_w(0, X, S)
+    assert info == 0
+    res = {}
+    try:
+        for mode, mh in ((1, 1), (2, 1), (2, 2)):
+            dev.set_option("prec_dense", mode)
+            dev.set_option("matvec_h", mh)
+            assert dev.prec_setup(1, 1, 1) == 0
+            n0 = dev.count("prec_dense_apply")
+            mx = dev.prec_apply(g["x"])
+            assert (dev.count("prec_dense_apply") > n0) == (mode == 2)
+            res[(mode, mh)] = (mx, [dev.pcg(g["h"], float(tol)) for tol in g["cg_tols"]])
+    finally:
+        dev.set_option("prec_dense", 0)
+        dev.set_option("matvec_h", 0)
+    smw = res[(1, 1)]
+    assert relerr(smw[0], g["MyM_x"]) < 1e-10
+    for key in ((2, 1), (2, 2)):
+        assert relerr(res[key][0], smw[0]) < 1e-11
+        assert relerr(res[key][0], g["MyM_x"]) < 1e-10
+        for (x1, e1, i1), (x2, e2, i2), ec, it, tol in zip(smw[1], res[key][1], g["cg_exit"], g["cg_iters"], g["cg_tols"]):
+            assert (e1, i1) == (e2, i2) == (int(ec), int(it))
+            assert relerr(x2, x1) < 0.1 * float(tol) + 1e-11

@@ -14,4 +14,6 @@ for x in o.solver.trace:
     known = sum(g.values()) + x.get("find_step_ms", 0.0) + x.get("lyap_ms", 0.0)
     print("it %2d total %6.2f | %s | find_step %5.2f lyap %5.2f (%d) | other %5.2f | lanczos %s in %s runs" % (
         x["iter"], x["itertime"] * 1e3, " ".join("%s %.2f" % (k[:6], v) for k, v in g.items() if v), x.get("find_step_ms", 0.0),
-        x.get("lyap_ms", 0.0), x.get("lyap_steps", 0), x["itertime"] * 1e3 - known, x.get("lanczos_steps"), x.get("lanczos_runs")))
+        x.get("lyap_ms", 0.0), x.get("lyap_steps", 0), x["itertime"] * 1e3 - known, x.get("lanczos_steps"), x.get("lanczos_runs")),
+        "| prec lanczos %s plain %s dense %s | cg %d+%d hop %s/%s" % (x.get("prec_lanczos_steps"), x.get("lanczos_plain"), x.get("prec_dense_build"),
+                                                                   x["cg_pre"], x["cg_cor"], x.get("hop_assemble"), x.get("hop_matvec")))
