@@ -107,6 +107,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "pair_lanes")) c->opt.pair_lanes = (int)value;
   else if (!strcmp(key, "matvec_sparse")) c->opt.matvec_sparse = (int)value;
   else if (!strcmp(key, "prec_dense")) c->opt.prec_dense = (int)value;
+  else if (!strcmp(key, "wmw_pattern_min")) c->opt.wmw_pattern_min = std::max(2, (int)value);
   else if (!strcmp(key, "matvec_h")) { c->opt.matvec_h = (int)value; c->hop_version = -1; }
   else if (!strcmp(key, "comm_fail_ensure")) lrn::comm_inject_ensure_failure(c);      // test hook (tests/test_gpu_comm.py)
   else if (!strcmp(key, "pcg_lookahead")) c->opt.pcg_lookahead = std::max(0, std::min(8, (int)value));
@@ -122,9 +123,12 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "shard_products_min")) c->opt.shard_products_min = std::max(16, (int)value);
   else if (!strcmp(key, "ns_l0")) c->opt.ns_l0 = value;
   else if (!strcmp(key, "ns_maxit")) c->opt.ns_maxit = (int)value;
+  else if (!strcmp(key, "ns_lanczos")) c->opt.ns_lanczos = (int)value;
+  else if (!strcmp(key, "ns_lanczos_min")) c->opt.ns_lanczos_min = std::max(8, (int)value);
   else if (!strcmp(key, "ns_dual")) c->opt.ns_dual = (int)value;
   else if (!strcmp(key, "lyap_tol")) c->opt.lyap_tol = value;
   else if (!strcmp(key, "lyap_maxit")) c->opt.lyap_maxit = (int)value;
+  else if (!strcmp(key, "lyap_form")) c->opt.lyap_form = (int)value;
   else if (!strcmp(key, "shard_bs")) { if (value < 0) return LRN_ERR_ARG; c->shard_bs_opt = (int)value; lrn::update_shard_bs(c); }
   else if (!strcmp(key, "reset_timing")) { c->timing.clear(); c->counts.clear(); }
   else return set_error(c, LRN_ERR_ARG, "unknown option %s", key);

@@ -893,7 +893,7 @@ int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
   const int m = b.msz;
   if (products_sharded(c, c->stream, m)) {      // P = W M' (M symmetric), Z = P W' (W symmetric): column blocks + all-gather
     LRN_TRY(pgemm_nt(c, c->stream, m, b.W.as<double>(), M, P));
-    return pgemm_nt(c, c->stream, m, P, b.W.as<double>(), Z);
+    return pgemm_nt_sym(c, c->stream, m, P, b.W.as<double>(), Z);
   }
   GemmDesc g1;     // P = W M   (M symmetric: read as M[n + k*m] -> direct-to-LDS path)
   g1.A = b.W.as<double>(); g1.sAm = 1; g1.sAk = m;
@@ -901,12 +901,31 @@ int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z) {
   g1.C = P; g1.sCm = 1; g1.sCn = m;
   g1.M = g1.N = g1.K = m;
   LRN_TRY(gemm(c->stream, g1));
+  if (m >= 1500) return gemm_nt_sym(c->stream, m, P, b.W.as<double>(), Z);      // Z = P W symmetric: lower tiles + mirror
   GemmDesc g2;     // Z = P W   (W symmetric)
   g2.A = P; g2.sAm = 1; g2.sAk = m;
   g2.B = b.W.as<double>(); g2.sBk = m; g2.sBn = 1;
   g2.C = Z; g2.sCm = 1; g2.sCn = m;
   g2.M = g2.N = g2.K = m;
   return gemm(c->stream, g2);
+}
+
+// AA vec(W M W) for a dense symmetric M when every constraint of the block is sparse (C5: 9 entries each): the entries
+// of Z = W M W are needed on the pattern of the constraints only -- N = M W is one product, Z[p,q] = W(:,p) . N(:,q) one
+// wave per stored entry (the kernels of the pattern-restricted CG operator above) -- instead of the second n^3 product.
+bool wmw_pattern_ok(const lrn_ctx* c, const LmiBlock& b) {
+  return b.sp_ok && b.nd == 0 && b.msz >= c->opt.wmw_pattern_min && b.have_W;
+}
+
+int aa_times_wmw_pattern(lrn_ctx* c, LmiBlock& b, const double* M, double* N, double* y) {
+  const int m = b.msz;
+  LRN_TRY(pgemm_nt(c, c->stream, m, M, b.W.as<double>(), N));                   // N = M W' = M W
+  hipLaunchKernelGGL(sp_dot_wave_kernel, dim3((unsigned)((b.ncq + 3) / 4)), dim3(256), 0, c->stream, b.cq_q.as<long>(),
+                     b.pc_t.as<int>(), b.ncq, b.W.as<double>(), N, m, 0, m, 1, b.Zs.as<double>());
+  hipLaunchKernelGGL(sp_aa_times_kernel, dim3((b.npos_nz + 3) / 4), dim3(256), 0, c->stream, b.ent_ptr.as<long>(),
+                     b.ent_c.as<int>(), b.ent_v.as<double>(), b.ent_t.as<int>(), b.Zs.as<double>(), 0, m, b.npos_nz,
+                     b.sigma_d.as<int>(), y);
+  return LRN_OK;
 }
 
 int ensure_m(lrn_ctx* c, int m) {

@@ -101,10 +101,13 @@ struct LrnOptions {
   int nt_mode = 1;                // lrn_ip_prepare_w: 1 = eigen-free NT scaling (Newton-Schulz square roots of K = L_X'SL_X, Lyapunov
                                   // solve for the second-order term; falls back to the SVD when it does not converge), 0 = SVD always
   double ns_l0 = 2e-3;            // Newton-Schulz schedule: assumed lower end of spec(K)/c (slower, never wrong, when cond(K) is larger)
+  int ns_lanczos = 1;             // Newton-Schulz: scale c and schedule end l from a 24-step Lanczos run on K (blocks of side >= ns_lanczos_min)
+  int ns_lanczos_min = 1500;
   int ns_dual = -1;               // Newton-Schulz: transposed twins from the GEMM epilogue (1), a transpose pass (0), auto (-1)
   int ns_maxit = 40;              // Newton-Schulz steps before the SVD fallback
   double lyap_tol = 1e-12;        // relative residual of the Lyapunov CG (second-order term of the corrector)
   int lyap_maxit = 300;
+  int lyap_form = 1;              // 1: the better conditioned equivalent equation (Yh/s + s Zh) R + R (.) = C/s + s Zh C Zh, 0: Yh R + R Yh = C
   int pair_lanes = 0;             // pair_wave_kernel: lanes per Schur entry, 0 auto (16 for short products), 16, 64
   int matvec_sparse = 0;          // 0 auto, 1 dense GEMM path, 2 sparse path whenever the pattern allows
   int shard_products = 1;         // multi-GPU: the n^3 products of the resident path (Newton-Schulz, Lyapunov CG, step) by
@@ -112,6 +115,8 @@ struct LrnOptions {
                                   // all-gather costs more than the product)
   int prec_dense = 0;             // H_alpha inside lrn_pcg as ONE dense symmetric matrix M^-1 (nvar <= 8192): 0 auto (cost model), 1 never, 2 always
                                   // (also in lrn_prec_apply)
+  int wmw_pattern_min = 1500;     // right-hand sides AA vec(W M W) with all constraints sparse: from this side on through the
+                                  // pattern entries of W M W (one n^3 product instead of two)
   int matvec_h = 0;               // CG operator through the assembled Schur matrix (hop.hip): 0 auto (cost model), 1 never
                                   // (the matrix-free MyA always), 2 always
   int pcg_lookahead = 2;          // lrn_pcg: iterations the host queues beyond the one whose convergence test it has read

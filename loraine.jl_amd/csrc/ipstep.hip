@@ -563,6 +563,39 @@ static int lz_collect(lrn_ctx* c, LzRun& r) {
   return LRN_OK;
 }
 
+// Both ends of the spectrum of a symmetric matrix from `nsteps` plain Lanczos steps: lo = smallest Ritz value (an UPPER
+// bound of lambda_min), hi = largest Ritz value, res_hi = residual norm of its Ritz pair (an eigenvalue lies within res_hi
+// of hi).  For the scaling of the Newton-Schulz iteration (prepw.hip), where a wrong value costs steps, not correctness.
+int lanczos_ends(lrn_ctx* c, const double* M, int n, int nsteps, double* lo, double* hi, double* res_hi) {
+  LzRun r;
+  LRN_TRY(lz_begin(c, r, M, n, c->stream, c->lzbuf));
+  r.mmax = std::min(r.mmax, std::max(4, nsteps));
+  lz_start(r);
+  std::vector<double> hab;
+  while (r.m < r.mmax) {
+    lz_launch(r);
+    r.m = r.m1;
+  }
+  const int m = r.m;
+  hab.resize(2 * (size_t)m);
+  LRN_TRY(copy_out(c, hab.data(), r.ab, (size_t)2 * m * 8));
+  std::vector<double> a(m), b(m), an(m);
+  int mm_ = m;
+  double scale = 0.0;
+  for (int j = 0; j < m; ++j) {
+    a[j] = hab[2 * j]; b[j] = hab[2 * j + 1]; an[j] = -a[j];
+    scale = std::max(scale, std::fabs(a[j]) + std::fabs(b[j]));
+    if (!(b[j] > 1e-14 * scale) && j + 1 < m) { mm_ = j + 1; break; }      // invariant subspace: the Ritz values are exact
+  }
+  if (!(scale == scale) || mm_ < 1) return set_error(c, LRN_ERR_STATE, "lanczos_ends: not a finite matrix");
+  *lo = tridiag_min(a, b, mm_);
+  const double top = -tridiag_min(an, b, mm_);       // largest eigenvalue of T = - smallest of -T (same off-diagonal)
+  *hi = top;
+  *res_hi = mm_ < m ? 0.0 : ritz_residual(an, b, mm_, -top);
+  c->counts["lanczos_ends_steps"] += m;
+  return LRN_OK;
+}
+
 int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, bool* converged = nullptr,
                double* scale_out = nullptr) {
   if (converged) *converged = true;
@@ -795,19 +828,94 @@ __global__ __launch_bounds__(256) void lyap_p_kernel(const double* __restrict__ 
 // R with Yh R + R Yh = Cm (Yh symmetric positive definite, Cm symmetric) by conjugate gradients in the Frobenius inner
 // product: one product Yh p per step (the other half of the operator is its transpose), all scalars stay on the device,
 // the host reads the residual history once per batch of steps.  Cm is used as the residual and destroyed.
+//
+// Round 4 -- the SAME solution from a better conditioned equation (option lyap_form = 1, default).  Zh = Yh^-1 is at hand
+// (the coupled Newton-Schulz iteration produces both), and multiplying  Yh R + R Yh = C  by Zh from both sides gives
+// Zh R + R Zh = Zh C Zh.  Any positive combination is again a Lyapunov equation for the same R:
+//     M R + R M = C / s + s Zh C Zh,      M = Yh / s + s Zh,
+// whose coefficient has the spectrum y / s + s / y: with s^2 = tr(Yh) / tr(Zh) (inside [y_min^2, y_max^2], free) its
+// condition number is ~ sqrt(cond(Yh)) / 2 and never above cond(Yh) / 2.  Still one product per CG step, two more for the
+// right-hand side; NumPy on spectra of cond(K) 1e2 / 1e3 / 1e4: 42 / 77 / 137 steps -> 14 / 21 / 29, same accuracy
+// (C5: 32-48 steps of a 10^4-cube product each, 1.1-1.6 s of a 2.8 s iteration).
+__global__ __launch_bounds__(256) void lyap_trace2_kernel(const double* __restrict__ Y, const double* __restrict__ Z, int n,
+                                                          double* __restrict__ sc) {
+  __shared__ double sh[8];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { a += Y[(size_t)i * n + i]; b += Z[(size_t)i * n + i]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = a; sh[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ty = sh[0] + sh[1] + sh[2] + sh[3], tz = sh[4] + sh[5] + sh[6] + sh[7];
+    double s = (ty > 0.0 && tz > 0.0) ? sqrt(ty / tz) : 1.0;
+    if (!(s > 0.0) || isinf(s)) s = 1.0;
+    sc[0] = s;
+    sc[1] = 1.0 / s;
+  }
+}
+
+// M = Y / s + s Z
+__global__ void lyap_mop_kernel(const double* __restrict__ Y, const double* __restrict__ Z, const double* __restrict__ sc,
+                                long total, double* __restrict__ Mop) {
+  const double s = sc[0], si = sc[1];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    Mop[e] = Y[e] * si + s * Z[e];
+}
+
+// C <- C / s + s (T + T') / 2   (T = Zh C Zh up to rounding asymmetry), by 32 x 32 tiles as symadd_kernel
+__global__ __launch_bounds__(256) void lyap_rhs_kernel(double* __restrict__ Cm, const double* __restrict__ T, int n,
+                                                       const double* __restrict__ sc) {
+  __shared__ double ta[32][33], tb[32][33];
+  const double s = sc[0], si = sc[1];
+  const int nt = (n + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (long t = blockIdx.x; t < (long)nt * nt; t += gridDim.x) {
+    const int bi = (int)(t % nt) * 32, bj = (int)(t / nt) * 32;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int i = bi + tx, j = bj + r;
+      ta[r][tx] = (i < n && j < n) ? T[(long)i + (long)j * n] : 0.0;
+      const int i2 = bj + tx, j2 = bi + r;
+      tb[r][tx] = (i2 < n && j2 < n) ? T[(long)i2 + (long)j2 * n] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+      const int i = bi + tx, j = bj + r;
+      if (i < n && j < n) {
+        const long e = (long)i + (long)j * n;
+        Cm[e] = Cm[e] * si + s * 0.5 * (ta[r][tx] + tb[tx][r]);
+      }
+    }
+  }
+}
+
 static int lyap_solve(lrn_ctx* c, LmiBlock& b, double* Cm, double* R, double* work, bool* ok, int* steps) {
   const int n = b.msz;
   const long nn = (long)n * n;
   hipStream_t st = c->stream;
-  const int maxit = std::max(8, c->opt.lyap_maxit);
+  const int maxit = std::max(2, c->opt.lyap_maxit);
   const int np = (int)std::min<long>(1024, (nn + 255) / 256);
-  LRN_TRY(ensure(c, b.lyap, ((size_t)2 * nn + 2 * 1024 + maxit + 16) * 8));
+  const bool combined = c->opt.lyap_form != 0;
+  LRN_TRY(ensure(c, b.lyap, ((size_t)(combined ? 3 : 2) * nn + 2 * 1024 + maxit + 16) * 8));
   double* p = b.lyap.as<double>();
   double* Ap = p + nn;
   double* part1 = Ap + nn;
   double* part2 = part1 + 1024;
   double* hist = part2 + 1024;
+  double* Mop = hist + maxit + 16;
   double* r = Cm;
+  const double* Cop = b.Yh.as<double>();             // coefficient matrix of the equation that is iterated on
+  const int ntile0 = (n + 31) / 32;
+  if (combined) {
+    double* sc = part2;                               // (two doubles, free until the first lyap_xr_kernel)
+    hipLaunchKernelGGL(lyap_trace2_kernel, dim3(1), dim3(256), 0, st, b.Yh.as<double>(), b.Zh.as<double>(), n, sc);
+    hipLaunchKernelGGL(lyap_mop_kernel, dim3(np), dim3(256), 0, st, b.Yh.as<double>(), b.Zh.as<double>(), sc, nn, Mop);
+    LRN_TRY(pgemm_nt(c, st, n, b.Zh.as<double>(), Cm, work));                 // Zh C   (C symmetric)
+    LRN_TRY(pgemm_nt(c, st, n, work, b.Zh.as<double>(), Ap));                 // Zh C Zh
+    hipLaunchKernelGGL(lyap_rhs_kernel, dim3((unsigned)std::min<long>(1024, (long)ntile0 * ntile0)), dim3(256), 0, st, Cm, Ap, n, sc);
+    Cop = Mop;
+  }
   LRN_HIP(c, hipMemsetAsync(R, 0, (size_t)nn * 8, st));
   LRN_HIP(c, hipMemcpyAsync(p, r, (size_t)nn * 8, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(dot_part_kernel, dim3(np), dim3(256), 0, st, r, (const double*)nullptr, nn, part1);
@@ -818,10 +926,11 @@ static int lyap_solve(lrn_ctx* c, LmiBlock& b, double* Cm, double* R, double* wo
   *ok = false;
   const int ntile = (n + 31) / 32;
   const int np1 = (int)std::min<long>(1024, (long)ntile * ntile);
+  int batch = std::min(maxit, n >= 2000 ? 6 : 8);      // first look at the residual history
   while (k < maxit) {
-    const int k1 = std::min(maxit, k + (k == 0 ? 8 : 4));
+    const int k1 = std::min(maxit, k + batch);
     for (; k < k1; ++k) {
-      LRN_TRY(pgemm_nt(c, st, n, b.Yh.as<double>(), p, work));
+      LRN_TRY(pgemm_nt(c, st, n, Cop, p, work));
       hipLaunchKernelGGL(symadd_kernel, dim3(np1), dim3(256), 0, st, work, n, 1.0, Ap, p, part1);
       hipLaunchKernelGGL(lyap_xr_kernel, dim3(np), dim3(256), 0, st, part1, np1, hist, k, p, Ap, R, r, nn, part2);
       hipLaunchKernelGGL(lyap_p_kernel, dim3(np), dim3(256), 0, st, part2, np, hist, k, r, p, nn);
@@ -830,6 +939,15 @@ static int lyap_solve(lrn_ctx* c, LmiBlock& b, double* Cm, double* R, double* wo
     LRN_HIP(c, hipStreamSynchronize(st));
     if (!(h[k] == h[k])) break;                                   // NaN
     if (h[0] == 0.0 || h[k] <= tol2 * h[0]) { *ok = true; break; }
+    // how many more steps at the rate of the last two (CG only gets faster): queue that many before the next look --
+    // a step is one n^3 product (31 ms at msz 10^4: none to waste), a look is a host round trip (20 us: too many at 800)
+    batch = n >= 2000 ? 2 : 4;
+    if (k >= 2 && h[k] > 0.0 && h[k] < h[k - 2]) {
+      const double f = 0.5 * std::log(h[k - 2] / h[k]);           // decrement of log ||r||^2 per step
+      const double m = std::log(h[k] / (tol2 * h[0])) / f;
+      const int lo_b = n >= 2000 ? 1 : 2;
+      batch = std::max(lo_b, std::min(8, (int)std::floor(0.9 * m + 0.5)));
+    }
   }
   if (steps) *steps = k;
   return LRN_OK;
@@ -963,6 +1081,11 @@ extern "C" int lrn_ip_rhs_pred2(lrn_ctx* c, double* aax_out, double* out) {
     const long mm_ = (long)b.msz * b.msz;
     hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t0.as<double>(), 1.0, b.Rd.as<double>(),
                        1.0, b.S.as<double>(), 0.0, (const double*)nullptr, mm_);
+    if (wmw_pattern_ok(c, b)) {          // every constraint sparse: W M W only where AA reads it (one product instead of two)
+      LRN_TRY(aa_times(c, b, b.X.as<double>(), c->v2.as<double>()));
+      LRN_TRY(aa_times_wmw_pattern(c, b, b.t0.as<double>(), b.t1.as<double>(), c->v1.as<double>()));
+      continue;
+    }
     LRN_TRY(wmw(c, b, b.t0.as<double>(), b.t1.as<double>(), b.t2.as<double>()));
     LRN_TRY(aa_times2(c, b, b.X.as<double>(), c->v2.as<double>(), b.t2.as<double>(), c->v1.as<double>()));
   }
@@ -983,6 +1106,13 @@ extern "C" int lrn_ip_rhs_corr(lrn_ctx* c, double sigma_mu, double* out) {
     const long mm_ = (long)m * m;
     if (b.nt_free) {
       // G (G'RdG + D - sigma_mu/D - RNT) G' = W Rd W + X - sigma_mu Si - G RNT G'
+      if (wmw_pattern_ok(c, b)) {        // AA vec(W Rd W) on the pattern, AA vec(X - sigma_mu Si - G RNT G') by itself
+        LRN_TRY(aa_times_wmw_pattern(c, b, b.Rd.as<double>(), b.t1.as<double>(), c->v1.as<double>()));
+        hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t0.as<double>(), 1.0, b.X.as<double>(), -sigma_mu,
+                           b.Si.as<double>(), -1.0, b.Qm.as<double>(), mm_);
+        LRN_TRY(aa_times(c, b, b.t0.as<double>(), c->v1.as<double>()));
+        continue;
+      }
       LRN_TRY(wmw(c, b, b.Rd.as<double>(), b.t1.as<double>(), b.t2.as<double>()));
       hipLaunchKernelGGL(lin3_kernel, dim3(nbk(mm_)), dim3(256), 0, c->stream, b.t0.as<double>(), 1.0, b.t2.as<double>(), 1.0,
                          b.X.as<double>(), -sigma_mu, b.Si.as<double>(), mm_);
@@ -1032,12 +1162,22 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
       // TX = L_X^-1 dX L_X^-T = -I - T (+ sigma_mu K^-1 + R), dX = L_X TX L_X'                  (:253-257)
       const unsigned gs = (unsigned)std::min<long>(1024, ((long)(m + 31) / 32) * ((m + 31) / 32));
       LRN_TRY(pgemm_nt(c, c->stream, m, b.LXt.as<double>(), b.delS.as<double>(), t0, GEMM_KFROM_M));    // L_X' upper triangular
-      LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.LXt.as<double>(), t1, GEMM_KFROM_N));
-      hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, b.Bs.as<double>(), (const double*)nullptr,
-                         (double*)nullptr);
+      // (both second products are symmetric in exact arithmetic: from msz 1500 on the lower tiles + mirror, half the work;
+      // below, the full product and the average of the two triangles)
+      if (m >= 1500) {
+        LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXt.as<double>(), b.Bs.as<double>(), 1.0, GEMM_KFROM_N));
+      } else {
+        LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.LXt.as<double>(), t1, GEMM_KFROM_N));
+        hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, b.Bs.as<double>(), (const double*)nullptr,
+                           (double*)nullptr);
+      }
       LRN_TRY(pgemm_nt(c, c->stream, m, b.Zh.as<double>(), b.Bs.as<double>(), t0));
-      LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.Zh.as<double>(), t1, 0, 1.0 / b.ns_c));
-      hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, t3, (const double*)nullptr, (double*)nullptr);
+      if (m >= 1500) {
+        LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.Zh.as<double>(), t3, 1.0 / b.ns_c));
+      } else {
+        LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.Zh.as<double>(), t1, 0, 1.0 / b.ns_c));
+        hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, t3, (const double*)nullptr, (double*)nullptr);
+      }
       hipLaunchKernelGGL(tx_kernel, dim3(g), dim3(256), 0, c->stream, t3, sigma_mu / b.ns_c, b.Ki.as<double>(),
                          predict ? (const double*)nullptr : b.RNT.as<double>(), b.TX.as<double>(), m);
       LRN_TRY(pgemm_nt(c, c->stream, m, b.LXf.as<double>(), b.TX.as<double>(), t0, GEMM_KTO_M));        // L_X lower triangular

@@ -5,6 +5,9 @@ namespace lrn {
 int ensure_m(lrn_ctx* c, int m);                                            // c->m0..m2 >= msz^2
 int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z);          // Z = W M W (M symmetric)
 int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y);          // y += AA vec(Z)
+// y += AA vec(W M W) through the entries of W M W the (all sparse) constraints read: N (work) = M W, then dots on the pattern
+bool wmw_pattern_ok(const lrn_ctx* c, const LmiBlock& b);
+int aa_times_wmw_pattern(lrn_ctx* c, LmiBlock& b, const double* M, double* N, double* y);
 int aa_times2(lrn_ctx* c, LmiBlock& b, const double* Z1, double* y1, const double* Z2, double* y2);   // both, one pass over dense data
 int aat_to_mat(lrn_ctx* c, LmiBlock& b, const double* x, double* M);        // M = mat(AA' x)
 int prepare_w_block(lrn_ctx* c, LmiBlock& b, int* info);                    // NT scaling from b.X, b.S (SVD route)
@@ -31,6 +34,8 @@ int pgemm_nt_sym(lrn_ctx* c, hipStream_t st, int n, const double* A, const doubl
 // k largest eigenpairs (ascending), smallest eigenvalue and trace of a dense symmetric matrix
 int lanczos_extremes(lrn_ctx* c, const double* M, int n, int k, double* lam_top, double* U_top, double* lam_min,
                      double* trace, int* steps_out);
+// both ends of the spectrum from nsteps plain Lanczos steps (ipstep.hip): lo >= lambda_min, an eigenvalue within res_hi of hi
+int lanczos_ends(lrn_ctx* c, const double* M, int n, int nsteps, double* lo, double* hi, double* res_hi);
 // single-launch Lanczos steps [j0, j1) keeping every q_j (ipstep.hip); PA2: 2 * ceil(n / 16) doubles, Y2: 2 n doubles
 int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
                    double* ab);

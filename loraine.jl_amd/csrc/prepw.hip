@@ -280,6 +280,11 @@ __global__ __launch_bounds__(256) void normc_kernel(const double* __restrict__ c
   }
 }
 
+__global__ void set_sc_kernel(double* __restrict__ sc, double cval) {
+  sc[0] = cval;
+  sc[1] = 1.0 / cval;
+}
+
 __global__ void scale_dev_kernel(const double* __restrict__ K, const double* __restrict__ sc, long total,
                                  double* __restrict__ Y) {
   const double f = sc[1];
@@ -559,11 +564,30 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   LRN_TRY(pgemm_nt_sym(c, st, n, Pm, Pm, Tm, 1.0));                                        // K = CC' CC
   hipLaunchKernelGGL(colnorm_kernel, dim3(n), dim3(256), 0, st, Tm, n, colsum, colsq);
   hipLaunchKernelGGL(normc_kernel, dim3(1), dim3(256), 0, st, colsum, colsq, n, sc);
+  // Round 4: where a step of the iteration is expensive (three n^3 products; msz >= ns_lanczos_min) the scale c and the
+  // lower end l of the schedule come from a short Lanczos run on K instead of norm bounds and a fixed guess: the norm bound
+  // min(||K||_1, ||K||_F) is 1.4-7 x lambda_max on the iterates of theta1 / control1 / maxG11 (more as msz grows) and the
+  // assumed l^2 = 2e-3 four to forty times below lambda_min / lambda_max -- two to three steps of eight to ten.  c keeps a
+  // margin over the Ritz value (an eigenvalue above c would turn negative under the scaled map: the residual test then
+  // sends the iteration to the SVD route); l may be wrong in either direction (costs steps, never correctness).
+  double ell2 = std::min(std::max(c->opt.ns_l0, 1e-12), 0.25);
+  if (c->opt.ns_lanczos != 0 && n >= c->opt.ns_lanczos_min) {
+    double lo = 0.0, hi = 0.0, rh = 0.0;
+    LRN_TRY(lanczos_ends(c, Tm, n, 24, &lo, &hi, &rh));
+    double cn[2] = {0.0, 0.0};
+    LRN_TRY(copy_out(c, cn, sc, 16));                              // the norm bound (always valid)
+    const double cl = 1.05 * (hi + rh);
+    if (hi > 0.0 && cl > 0.0 && cl < cn[0]) {
+      hipLaunchKernelGGL(set_sc_kernel, dim3(1), dim3(1), 0, st, sc, cl);
+      if (lo > 0.0) ell2 = std::min(0.25, std::max(ell2, 0.5 * lo / cl));
+      c->counts["ns_lanczos_scaled"] += 1;
+    }
+  }
   hipLaunchKernelGGL(scale_dev_kernel, dim3(ge), dim3(256), 0, st, Tm, sc, (long)nn, Y);
   toc(c, "prepw_gemm");
   tic(c);
   // Newton-Schulz: the planned steps are the scaled ones plus the plain steps of the quadratic phase
-  double ell = std::sqrt(std::min(std::max(c->opt.ns_l0, 1e-12), 0.25));
+  double ell = std::sqrt(ell2);
   double *Yc = Y, *Ytc = Yt0, *Zc = Z, *Ztc = Zt0;        // current set (Y, Y', Z, Z')
   double *Yn = Ya, *Ytn = Yta, *Zn = Za, *Ztn = Zta;      // next set
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, Yc, n, Ytc);

@@ -251,3 +251,27 @@ def test_halpha_as_one_dense_matrix_equals_the_smw_apply(dev):
         for (x1, e1, i1), (x2, e2, i2), ec, it, tol in zip(smw[1], res[key][1], g["cg_exit"], g["cg_iters"], g["cg_tols"]):
             assert (e1, i1) == (e2, i2) == (int(ec), int(it))
             assert relerr(x2, x1) < 0.1 * float(tol) + 1e-11
+
+
+def test_right_hand_sides_through_the_pattern_of_the_constraints(dev):
+    """makeRHS and the corrector right-hand side (reference src/makeBBBB.jl:221-228, src/predictor_corrector.jl:186) need
+    W M W only at the entries the constraints read; with every constraint sparse (C5) the second n^3 product is replaced by
+    dots on the pattern (by default from msz 1500 on; forced here): same trajectory."""
+    from loraine_jl_amd import resident
+    from loraine_jl_amd.synthetic import LowRankProblem
+    P = LowRankProblem(120, 300, 3, seed=4)
+    model = P.model()
+    out = {}
+    for forced in (0, 1):
+        dev.set_option("wmw_pattern_min", 8 if forced else 1500)
+        try:
+            s, ha = resident.load(model, dict(kit=1, preconditioner=2, erank=3, verb=0, eDIMACS=1e-7, tol_cg_min=1e-10, tol_cg=1e-10), device=dev)
+            s.solve(ha)
+        finally:
+            dev.set_option("wmw_pattern_min", 1500)
+        assert s.status == 1
+        out[forced] = [t["primal_obj"] for t in s.trace]
+    assert len(out[0]) == len(out[1])
+    for a, b in zip(out[0], out[1]):
+        assert a == pytest.approx(b, rel=1e-8, abs=1e-10)
+    assert abs(float(model.b @ np.ravel(s.y)) - P.optimum) < 1e-6 * (1 + abs(P.optimum))

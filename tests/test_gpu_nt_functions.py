@@ -163,7 +163,7 @@ def _random_model(m, nvar, seed):
     return lo.make_model([A], rng.standard_normal(nvar), 0.0, None, None)
 
 
-@pytest.mark.parametrize("nt_mode", [1, 0])
+@pytest.mark.parametrize("nt_mode", [1, 0, 2])
 @pytest.mark.parametrize("cond", [1e6, 1e9, 1e12])
 def test_one_iteration_function_by_function_on_ill_conditioned_iterates(dev, cond, nt_mode):
     """Synthetic X, S with cond(X) = cond(S) from 1e6 to 1e12.  The oracle's own SVD route loses cond * eps here (both device
@@ -173,10 +173,17 @@ def test_one_iteration_function_by_function_on_ill_conditioned_iterates(dev, con
     X, S = _near_central_path(m, cond, 11)
     y = 0.1 * np.random.default_rng(5).standard_normal(nvar)
     st = _oracle_step(model, X, S, y, dict(kit=0))
+    # nt_mode 2 (test only): the eigen-free route with the Newton-Schulz scale and schedule taken from a Lanczos run on K
+    # (round 4; by default from msz 1500 on) at this size
+    if nt_mode == 2:
+        dev.set_option("ns_lanczos_min", 8)
     try:
-        e = _device_step(dev, model, X, S, y, st, nt_mode)
+        e = _device_step(dev, model, X, S, y, st, 1 if nt_mode == 2 else nt_mode)
+        if nt_mode == 2:
+            assert dev.count("ns_lanczos_scaled") > 0
     finally:
         dev.set_option("nt_mode", 1)
+        dev.set_option("ns_lanczos_min", 1500)
     tol = max(1e-10, 1e-16 * cond)          # measured 2e-11 / 1.3e-8 / 1.6e-5 at cond 1e6 / 1e9 / 1e12, the same on both routes
     _check(e, tol, max(1e-9, 4 * tol), f"cond={cond:g} nt_mode={nt_mode}")
 
@@ -217,10 +224,10 @@ def _run(path, device, **opts):
 
 
 @pytest.mark.parametrize("name,opts", [("theta1", dict(kit=0, eDIMACS=1e-6, initpoint=1)), ("control1", dict(kit=0, eDIMACS=1e-6))])
-@pytest.mark.parametrize("knob,value,counter", [("ns_maxit", 4, "ns_fallback"), ("lyap_maxit", 8, "lyap_fallback")])
+@pytest.mark.parametrize("knob,value,counter", [("ns_maxit", 4, "ns_fallback"), ("lyap_maxit", 3, "lyap_fallback")])
 def test_forced_fallbacks_keep_the_oracle_trajectory(dev, name, opts, knob, value, counter):
     """`ns_maxit = 4`: Newton-Schulz cannot converge -> the SVD route runs for the iteration (prepw.hip `ns_fallback`).
-    `lyap_maxit = 8`: the Lyapunov CG of the second-order term gives up -> the SVD quantities are formed in the middle of
+    `lyap_maxit = 3`: the Lyapunov CG of the second-order term gives up -> the SVD quantities are formed in the middle of
     the iteration, after the predictor's directions came from the other route (ipstep.hip `lyap_fallback`).  Both must
     leave the per-iteration trace within 1e-8 of the oracle's."""
     path = os.path.join(GOLD, f"{name}.dat-s")
@@ -276,3 +283,26 @@ def test_jacobi_early_stop_with_clustered_singular_values(dev, width):
     print("width", width, {k: ["%.1e" % v for v in r] for k, r in res.items()})
     for r in res.values():
         assert max(r) < 1e-10
+
+
+@pytest.mark.parametrize("name,opts", [("theta1", dict(kit=0, eDIMACS=1e-6, initpoint=1)), ("control1", dict(kit=0, eDIMACS=1e-6)),
+                                       ("maxG11", dict(kit=0, datarank=-1))])
+def test_both_forms_of_the_lyapunov_equation_give_the_same_solve(dev, name, opts):
+    """Round 4: the second-order term of the corrector from  (Yh/s + s Zh) R + R (Yh/s + s Zh) = C/s + s Zh C Zh  (default)
+    instead of  Yh R + R Yh = C  (`lyap_form = 0`): the same R, so the same trajectory (objectives of every iteration to
+    1e-9), in a fraction of the CG steps."""
+    path = os.path.join(GOLD, f"{name}.dat-s")
+    runs = {}
+    for form in (0, 1):
+        dev.set_option("lyap_form", form)
+        try:
+            o = _run(path, dev, **opts)
+        finally:
+            dev.set_option("lyap_form", 1)
+        assert o.termination_status() == "OPTIMAL"
+        runs[form] = (o.solver.iter, [t["primal_obj"] for t in o.solver.trace], sum(t["lyap_steps"] for t in o.solver.trace))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert a == pytest.approx(b, rel=1e-9, abs=1e-10)
+    print(name, "Lyapunov CG steps per solve:", runs[0][2], "->", runs[1][2])
+    assert runs[1][2] < runs[0][2]
