@@ -87,7 +87,19 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * "ns_maxit", "ns_dual" (-1 auto / 1 / 0: transposed twins of the products from the GEMM epilogue or a transpose pass),
  * "lyap_tol", "lyap_maxit" (relative residual / step limit of the Lyapunov CG),
  * "prec_inv" (H_alpha: -1 auto / 1 / 0: SMW core through an explicit inverse + one refinement step, or two triangular solves),
- * "shard_passes" (multi-GPU, 1: the passes over dense constraint data in AA*vec(.) / mat(AA'x) split by rank), "reset_timing". */
+ * "shard_passes" (multi-GPU, 1: the passes over dense constraint data in AA*vec(.) / mat(AA'x) split by rank),
+ * "shard_products" / "shard_products_min" (multi-GPU, 1: the n^3 products of the resident path -- Newton-Schulz, Lyapunov CG,
+ * step and right-hand sides -- as column blocks + all-gather from matrix side shard_products_min = 4096 on),
+ * "matvec_h" (CG operator of lrn_pcg / lrn_matvec through the ASSEMBLED Schur matrix, one pass over its lower triangle per
+ * application: 0 = a static cost model decides once per NT scaling from the CG iterations of the previous one, 1 = never,
+ * 2 = always), "prec_dense" (H_alpha inside lrn_pcg as one dense symmetric matrix, nvar <= 8192: 0 cost model / 1 never /
+ * 2 always, also in lrn_prec_apply), "pcg_lookahead" (iterations lrn_pcg queues beyond the convergence test it has read,
+ * 0..8; the count and the result do not depend on it), "wmw_pattern_min" (right-hand sides AA vec(W M W) with all constraints
+ * sparse: from this matrix side on through the pattern entries of W M W), "lyap_form" (second-order term of the corrector:
+ * 1 = the better conditioned equivalent Lyapunov equation (Yh/s + s Zh) R + R (.) = C/s + s Zh C Zh, 0 = Yh R + R Yh = C),
+ * "ns_lanczos" / "ns_lanczos_min" (1: scale and schedule of the Newton-Schulz iteration from a 24-step Lanczos run on K for
+ * blocks of side >= ns_lanczos_min = 1500), "comm_fail_ensure" (test hook: the next exchange of this rank fails its buffer
+ * allocation), "reset_timing". */
 int lrn_set_option(lrn_ctx* ctx, const char* key, double value);
 /* multi-GPU: this context assembles the Schur columns it owns (block-cyclic) */
 int lrn_set_shard(lrn_ctx* ctx, int rank, int world);
@@ -140,7 +152,10 @@ int lrn_schur_import_full(lrn_ctx* ctx, const double* buf);
 int lrn_make_rhs(lrn_ctx* ctx, const double* Rp, const double* const* RdS, double* h);
 
 /* ---- CG operator and preconditioners (src/Solvers.jl:572-904) ------------------------- */
-/* Ax = sum AA vec(W mat(AA'x) W) + C_lin((X_lin.*S_lin_inv).*(C_lin'x))   (MyA, :582-614) */
+/* Ax = sum AA vec(W mat(AA'x) W) + C_lin((X_lin.*S_lin_inv).*(C_lin'x))   (MyA, :582-614).
+ * The same linear map is H x for the Schur matrix H of src/makeBBBB.jl:67-218: when lrn_pcg has chosen that form for the
+ * current NT scaling (or option "matvec_h" = 2) the library assembles H once per scaling with the kernels of
+ * lrn_schur_assemble and applies it as one bandwidth-bound pass over its lower triangle (csrc/hop.hip). */
 int lrn_matvec(lrn_ctx* ctx, const double* x, double* Ax);
 /* multi-GPU CG operator: this rank's share  AA[:, idx(R_g)] vec((W M W)[R_g,:])  of the mat-vec,
  * R_g = row block `rank` of `world` (lrn_set_shard); the caller all-reduces (sum) the nvar-vector. */
@@ -151,7 +166,10 @@ int lrn_prec_setup(lrn_ctx* ctx, int prec, int erank, int aamat, int* info);
 /* Mx = M^{-1} x (MyM :866-904, MyM_beta :670-672, MyM_no :620-622) */
 int lrn_prec_apply(lrn_ctx* ctx, const double* x, double* Mx);
 /* cg(A, h; tol, maxIter, precon) of ConjugateGradients.jl 0.1 (call sites
- * predictor_corrector.jl:134,235), device-resident. */
+ * predictor_corrector.jl:134,235), device-resident: the recurrence is two multi-workgroup launches per iteration, the
+ * relative-residual test runs on the device and the host reads it `pcg_lookahead` iterations behind the one it queues
+ * (iterations queued beyond the last one leave x untouched: exit code, count and x are those of the loop that tests after
+ * every step).  Operator: MyA matrix-free or through the assembled Schur matrix (see lrn_matvec). */
 int lrn_pcg(lrn_ctx* ctx, const double* h, double tol, int maxit, double* x, int* exit_code,
             int* iters);
 

@@ -683,7 +683,8 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   LRN_TRY(pgemm_nt(c, st, n, LX, Ztc, Pm, GEMM_KTO_M, 1.0));                             // (L_X lower triangular)
   LRN_TRY(pgemm_nt_sym(c, st, n, Pm, LX, b.W.as<double>(), 1.0 / std::sqrt(b.ns_c), GEMM_KTO_N));
   // (K/c)^-1 = Zh^2: the sigma_mu S^-1 term of the corrector in the L_X basis
-  LRN_TRY(pgemm_nt(c, st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
+  if (n >= 1500) LRN_TRY(pgemm_nt_sym(c, st, n, Zc, Ztc, b.Ki.as<double>(), 1.0));       // symmetric: lower tiles + mirror
+  else LRN_TRY(pgemm_nt(c, st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
   if (two) {                                                  // join: Si is complete when this returns
     LRN_HIP(c, hipEventRecord(c->evB, s2));
     LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
