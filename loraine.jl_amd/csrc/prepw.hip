@@ -543,16 +543,8 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   double* LSt = Zta;                                 // (free until the first Newton-Schulz step, which st orders after its reader)
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LS, n, LSt);
   if (two) LRN_HIP(c, hipEventRecord(c->evB, s2));
-  hipLaunchKernelGGL(eye_kernel, dim3(ge), dim3(256), 0, s2, LSi, n);
-  if (shp) {                                          // L_S^-1: each rank solves its block of the identity's columns
-    int c0, c1;
-    const int cb = shard_cols(c, n, &c0, &c1);
-    if (c1 > c0) LRN_TRY(trsm_left_lower(s2, LS, n, n, nullptr, false, LSi + (long)c0 * n, c1 - c0, n, tw2));
-    LRN_TRY(comm_allgather_cols(c, LSi, n, cb));
-  } else
-  LRN_TRY(trsm_left_lower(s2, LS, n, n, nullptr, false, LSi, n, n, tw2));
-  hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, s2, LSi, n, LSit);   // L_S^-T
-  LRN_TRY(pgemm_nt_sym(c, s2, n, LSit, LSit, b.Si.as<double>(), 1.0, GEMM_KFROM_M));          // L_S^-T upper triangular
+  // (round 4: S^-1 no longer through L_S^-1 -- a triangular solve with msz right-hand sides, 436 ms of a 2 s iteration at
+  // msz 10^4 -- but from what the iteration produces anyway: K = L_X' S L_X  =>  S^-1 = L_X K^-1 L_X', see the end)
   hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, st, LX, n, LXt);
   // K = CC' CC with CC = L_S' L_X (prepare_W.jl:39) -- NOT L_X' S L_X: with cond(X), cond(S) at 1e10 the entries of
   // |L_X'| |S| |L_X| are 1e10 times those of K and the explicit product has no correct digit left (measured: the
@@ -685,7 +677,10 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   // (K/c)^-1 = Zh^2: the sigma_mu S^-1 term of the corrector in the L_X basis
   if (n >= 1500) LRN_TRY(pgemm_nt_sym(c, st, n, Zc, Ztc, b.Ki.as<double>(), 1.0));       // symmetric: lower tiles + mirror
   else LRN_TRY(pgemm_nt(c, st, n, Zc, Ztc, b.Ki.as<double>(), 0, 1.0));
-  if (two) {                                                  // join: Si is complete when this returns
+  // Si = S^-1 = L_X K^-1 L_X' = L_X Ki L_X' / c  (prepare_W.jl:68): two products with the triangular factor, nothing inverted
+  LRN_TRY(pgemm_nt(c, st, n, LX, b.Ki.as<double>(), Pm, GEMM_KTO_M, 1.0));               // L_X Ki'  (Ki symmetric)
+  LRN_TRY(pgemm_nt_sym(c, st, n, Pm, LX, b.Si.as<double>(), 1.0 / b.ns_c, GEMM_KTO_N));
+  if (two) {                                                  // join (the transposes on the second stream)
     LRN_HIP(c, hipEventRecord(c->evB, s2));
     LRN_HIP(c, hipStreamWaitEvent(st, c->evB, 0));
   }

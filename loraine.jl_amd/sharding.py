@@ -223,8 +223,10 @@ class DistributedHotPath:
     (SURVEY.md 8e).  All this class does is create the library's communicator (csrc/comm.hip: RCCL, or host callbacks
     over a gloo group): from then on `lrn_schur_assemble` agrees on the path, checks every rank's outcome and exchanges
     on the library's stream (kit=0), and `lrn_pcg` all-reduces its nvar-vector (kit=1) -- the loop itself is unchanged,
-    which is what a Julia host gets from `LoraineHIP.comm_init!` as well.  prepare_W, find_step and the preconditioner
-    setup are replicas."""
+    which is what a Julia host gets from `LoraineHIP.comm_init!` as well.  From matrix side 4096 on the n^3 products of
+    prepare_W / find_step / the right-hand sides are computed as column blocks by the ranks and all-gathered inside the
+    library (option "shard_products"); below that size, the Cholesky factorisations, the Lanczos runs and the
+    preconditioner setup are replicas."""
 
     def __init__(self, solver, rank, world, group=None):
         self.rank, self.world, self.group = int(rank), int(world), group

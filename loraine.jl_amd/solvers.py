@@ -6,8 +6,10 @@ the preconditioned-CG solve -- executed on MI355X through the C ABI (`Device`).
 The reference's host language (Julia) is not available in this image, so this file plays
 the role of `Solvers.jl`: same option names, same status codes, same iteration logic.
 Everything marked [GPU] is one call into libloraine_hip.so; there is no CPU fallback for
-those calls.  Step-length search, residuals and DIMACS errors are still host NumPy
-(SURVEY.md section 8f "next" rows).
+those calls.  In THIS driver (host arrays, the reference's literal formulas) the step-length
+search, the residuals and the DIMACS errors are host NumPy; `resident.ResidentSolver` -- the
+default of `optimizer.Optimizer` -- overrides them with the device-resident `lrn_ip_*` calls
+(SURVEY.md section 8f rows 1-3), so that X, S and every msz x msz intermediate stay in HBM.
 """
 import math
 import time

@@ -36,26 +36,26 @@ def get(kpat, cname):
 
 with open(os.path.join(O, "l2_hit_rate.csv"), "w") as fh:
     fh.write("kernel,TCC_HIT_sum,TCC_MISS_sum,hit_rate\n")
-    for k1 in ("gemm_f64_lds_kernel<false>", "gemm_f64_lds_kernel<true>", "gemm_f64_kseg_lds_kernel<true, 4, 4>",
+    for k1 in ("gemm_f64_lds_kernel<false,", "gemm_f64_lds_kernel<true,", "gemm_f64_kseg_lds_kernel<true, 4, 4>",
                "gemm_f64_kseg_lds_kernel<true, 4, 5>"):
         h, m = get(k1, "TCC_HIT_sum"), get(k1, "TCC_MISS_sum")
         if h and m:
             fh.write('"%s",%.0f,%.0f,%.4f\n' % (k1, h["total"], m["total"], h["total"] / (h["total"] + m["total"])))
-STEPS = 2        # the PMC passes of profile_r02.sh run `bench.py --steps 1 --warmup 1`: two assemblies
+# per LAUNCH (the number of assemblies in a pass depends on the bench options: warm-up, steps, the `alongside` solve)
 for k1, label in (("gemm_f64_kseg_lds_kernel<true, 4, 4>", "GEMM3' (leading rows, 128 x 128 tiles)"),
                   ("gemm_f64_kseg_lds_kernel<true, 4, 5>", "GEMM3' strip (last 160 rows, 128 x 160 tiles)"),
-                  ("gemm_f64_lds_kernel<false>", "GEMM1'"),
-                  ("gemm_f64_lds_kernel<true>", "GEMM2'")):
+                  ("gemm_f64_lds_kernel<false,", "GEMM1'"),
+                  ("gemm_f64_lds_kernel<true,", "GEMM2'")):
     mf, gui = get(k1, "SQ_VALU_MFMA_BUSY_CYCLES"), get(k1, "GRBM_GUI_ACTIVE")
     if mf and gui:
         cyc = gui["total"] / 8.0
-        print("%s: %d launches per step, clock %.2f GHz, MFMA busy %.1f %% (over all its launches)" %
-              (label, gui["dispatches"] // STEPS, cyc / gui["total_duration_ns"], 100 * mf["total"] / (cyc * 1024)))
+        print("%s: %d launches in the pass, %.2f ms per launch, clock %.2f GHz, MFMA busy %.1f %% (over all its launches)" %
+              (label, gui["dispatches"], gui["mean_duration_ns"] / 1e6, cyc / gui["total_duration_ns"], 100 * mf["total"] / (cyc * 1024)))
     f, wr = get(k1, "FETCH_SIZE"), get(k1, "WRITE_SIZE")
     if f and wr:
-        step_bytes = (2.0 * f["total"] + wr["total"]) * 1024.0 / STEPS
-        print("%s: L2-miss traffic per step (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.1f GB, %.2f TB/s" %
-              (label, step_bytes / 1e9, step_bytes * STEPS / f["total_duration_ns"] / 1e3))
+        launch_bytes = (2.0 * f["mean"] + wr["mean"]) * 1024.0
+        print("%s: L2-miss traffic per launch (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.1f GB, %.2f TB/s" %
+              (label, launch_bytes / 1e9, launch_bytes / f["mean_duration_ns"] / 1e3))
     h, m = get(k1, "TCC_HIT_sum"), get(k1, "TCC_MISS_sum")
     if h and m:
         print("%s: L2 hit rate %.1f %%" % (label, 100 * h["total"] / (h["total"] + m["total"])))
