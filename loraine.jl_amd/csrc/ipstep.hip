@@ -214,7 +214,8 @@ __global__ __launch_bounds__(1024) void lz_step_kernel(const double* __restrict_
 // and then computes its 16 rows of y_j = M q_j and their share of q_j . y_j.  Vectors rotate through three (q) and two (y)
 // buffers so that nothing a workgroup still reads is overwritten inside a launch.  `do_symv` = 0: only finish step j-1
 // (last launch of a batch: the host needs alpha, beta of every step it reads).
-static constexpr int LZ_FUSED_MAX = 4096;
+static constexpr int LZ_FUSED_MAX = 16384;      // (round 4: 4096 -> 16384, q_j in up to 128 KB of LDS: at msz 10^4 the two-kernel
+                                                // step costs 0.21 + 0.24 ms -- its single-workgroup half sums 64 partial vectors)
 __device__ __forceinline__ void lz_fused_body(const double* __restrict__ M, int n, int nwg, int j, int do_symv, int qmod,
                                               double* Q3, double* Y2, double* PA2, double* ab, double* qs, double* sh) {
   const int t = threadIdx.x;
@@ -290,6 +291,20 @@ __global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict_
   lz_fused_body(M, n, nwg, j, do_symv, qmod, Q3, Y2, PA2, ab, qs, sh);
 }
 
+// more than 64 KB of dynamic LDS need the attribute (once per device); false: the two-kernel step is taken
+static bool lz_big_lds_ok() {
+  static bool done[64] = {}, ok[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!done[dev]) {
+    ok[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LZ_FUSED_MAX * 8) == hipSuccess;
+    if (!ok[dev]) (void)hipGetLastError();
+    done[dev] = true;
+  }
+  return ok[dev];
+}
+
 // ---- the same steps [j0, j1) in ONE launch (round 4; MEASURED SLOWER, kept behind LRN_LZ_PERSIST=1 for the record): a batch
 // of Lanczos steps is a chain of launches of 7-8 us each for 2-3 us of work.  Here the nwg <= 256 workgroups stay
 // resident and meet at a barrier after every step: a monotonic counter in global memory (release fence, one atomic add per
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(256) void lz_fused_multi_kernel(const double* __res
 // lanczos.hip (preconditioner setup); n <= LZ_FUSED_MAX.
 int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
                    double* ab) {
-  if (n > LZ_FUSED_MAX || j1 + 1 > qcap) return LRN_ERR_ARG;
+  if (n > LZ_FUSED_LIMIT || j1 + 1 > qcap) return LRN_ERR_ARG;
   const int nwg = (n + 15) / 16;
   const size_t lds = (size_t)n * 8;
   for (int j = j0; j < j1; ++j)
@@ -463,7 +478,7 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   r.cper = (n + r.nchunk - 1) / r.nchunk;
   r.nchunk = (n + r.cper - 1) / r.cper;
   static const bool no_fused = getenv("LRN_LZ_UNFUSED") != nullptr;
-  r.fused = !no_fused && n <= LZ_FUSED_MAX && n >= 32;
+  r.fused = !no_fused && n <= LZ_FUSED_MAX && n >= 32 && ((size_t)n * 8 <= 60 * 1024 || lz_big_lds_ok());
   r.nwg = (n + 15) / 16;
   LRN_TRY(ensure(c, buf, ((size_t)5 * n + (size_t)std::max(r.nchunk * n, 2 * r.nwg) + 2 * (size_t)r.mmax + 64) * 8));
   r.q = buf.as<double>();                 // fused: Q3 = q[0..3n)
@@ -474,7 +489,7 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   // (measurement knob, off: with two runs interleaved on two streams the per-step launches are hidden already and the
   // barrier -- device-scope release / acquire across eight L2s -- costs more than a launch: maxG11 find_step 1.0 -> 1.25 ms)
   static const bool persist_on = getenv("LRN_LZ_PERSIST") && atoi(getenv("LRN_LZ_PERSIST")) != 0;
-  r.persist = r.fused && persist_on && !c->lz_no_persist && r.nwg <= 256;
+  r.persist = r.fused && persist_on && !c->lz_no_persist && r.nwg <= 256 && (size_t)n * 8 <= 60 * 1024;
   r.flag = reinterpret_cast<unsigned*>(r.ab + 2 * (size_t)r.mmax + 8);      // (inside the 64 doubles of slack)
   r.bar_base = 0;
   return LRN_OK;
@@ -787,6 +802,17 @@ __device__ __forceinline__ double block_sum_parts(const double* __restrict__ par
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// out = (M + M') / 2: the tiled kernel above from msz 512 on (the element-wise one reads M' with stride n)
+static void sym_half(hipStream_t st, const double* M, double* out, int n) {
+  if (n >= 512) {
+    const long nt = (n + 31) / 32;
+    hipLaunchKernelGGL(symadd_kernel, dim3((unsigned)std::min<long>(1024, nt * nt)), dim3(256), 0, st, M, n, 0.5, out,
+                       (const double*)nullptr, (double*)nullptr);
+  } else {
+    hipLaunchKernelGGL(sym_kernel, dim3(nbk((long)n * n)), dim3(256), 0, st, M, out, n);
+  }
 }
 
 // alpha = rr_k / <p, Ap> (every workgroup sums the same partials in the same order); R += alpha p; r -= alpha Ap;
@@ -1202,7 +1228,7 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
       LRN_TRY(mm(c, m, t1, false, G, true, t2));
       hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, t0, 1.0, t2, 0.0, (const double*)nullptr, mm_);
     }
-    hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.delX.as<double>(), m);
+    sym_half(c->stream, t0, b.delX.as<double>(), m);
     // step lengths: eigmin of DDsi-scaled G' delS G and Gi delX Gi'   (:263-291)
     LRN_TRY(mm(c, m, Gi, false, b.delX.as<double>(), false, t0));
     LRN_TRY(mm(c, m, t0, false, Gi, true, t1));
@@ -1277,10 +1303,10 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
       b.chol_valid = false;
       hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, b.X.as<double>(), alpha[0],
                          b.delX.as<double>(), 0.0, (const double*)nullptr, mm_);
-      hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.X.as<double>(), m);
+      sym_half(c->stream, t0, b.X.as<double>(), m);
       hipLaunchKernelGGL(lin3_kernel, dim3(g), dim3(256), 0, c->stream, t0, 1.0, b.S.as<double>(), beta[0],
                          b.delS.as<double>(), 0.0, (const double*)nullptr, mm_);
-      hipLaunchKernelGGL(sym_kernel, dim3(g), dim3(256), 0, c->stream, t0, b.S.as<double>(), m);
+      sym_half(c->stream, t0, b.S.as<double>(), m);
     }
   }
   if (predict && trXnSn && c->nlmi > 0) LRN_TRY(copy_out(c, trXnSn, c->redout.p, (size_t)c->nlmi * 8));

@@ -20,7 +20,7 @@ def dev():
     d.close()
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 33, 50, 300, 801])
+@pytest.mark.parametrize("n", [1, 2, 7, 33, 50, 300, 801, 4500])      # 4500: q_j in more than 32 KB of LDS (round 4: fused up to 16384)
 @pytest.mark.parametrize("kind", ["indef", "spd", "cluster"])
 def test_lanczos_eigmin(dev, n, kind):
     rng = np.random.default_rng(n + len(kind))
