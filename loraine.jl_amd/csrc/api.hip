@@ -108,6 +108,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "matvec_sparse")) c->opt.matvec_sparse = (int)value;
   else if (!strcmp(key, "prec_dense")) c->opt.prec_dense = (int)value;
   else if (!strcmp(key, "wmw_pattern_min")) c->opt.wmw_pattern_min = std::max(2, (int)value);
+  else if (!strcmp(key, "profile_symv")) c->opt.profile_symv = (int)value;
   else if (!strcmp(key, "matvec_h")) { c->opt.matvec_h = (int)value; c->hop_version = -1; }
   else if (!strcmp(key, "comm_fail_ensure")) lrn::comm_inject_ensure_failure(c);      // test hook (tests/test_gpu_comm.py)
   else if (!strcmp(key, "pcg_lookahead")) c->opt.pcg_lookahead = std::max(0, std::min(8, (int)value));

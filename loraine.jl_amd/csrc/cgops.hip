@@ -1828,7 +1828,9 @@ static int op_apply(lrn_ctx* c, bool use_h, const double* p, double* Ap, double*
   const bool sharded = c->comm && c->world > 1;
   if (nq) *nq = 0;
   if (use_h) {
+    if (c->opt.profile_symv) tic(c);
     LRN_TRY(hop_apply(c, p, Ap, qpart, nq));
+    if (c->opt.profile_symv) toc(c, "hop_symv");        // (measurement: this rank's share of H x alone, tools/shard_balance_c5.py)
   } else if (sharded) {
     // one process per GPU: this rank's rows of W M W, then ONE all-reduce of the nvar-vector on this stream -- the
     // recurrence is replicated and stays on the device, as on one GPU

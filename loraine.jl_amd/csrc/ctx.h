@@ -117,6 +117,7 @@ struct LrnOptions {
                                   // (also in lrn_prec_apply)
   int wmw_pattern_min = 1500;     // right-hand sides AA vec(W M W) with all constraints sparse: from this side on through the
                                   // pattern entries of W M W (one n^3 product instead of two)
+  int profile_symv = 0;           // measurement: time every application of H x by itself (synchronises: not for solves)
   int matvec_h = 0;               // CG operator through the assembled Schur matrix (hop.hip): 0 auto (cost model), 1 never
                                   // (the matrix-free MyA always), 2 always
   int pcg_lookahead = 2;          // lrn_pcg: iterations the host queues beyond the one whose convergence test it has read

@@ -863,13 +863,30 @@ static int assemble_dense(lrn_ctx* c, LmiBlock& b) {
   return LRN_OK;
 }
 
+// owner ranges of one launch: the positions [lo, hi) cut at the column blocks this rank owns (all of them on one GPU) and
+// into pieces of at most `piece` owners -- the grid of a launch is (partners of its FIRST owner) x (owners), so a long
+// range launches workgroups that find no partner (half of them for one launch over the whole triangle), and a rank of a
+// sharded run would launch the seven eighths it does not own just to return (round 4: C5 at 8 ranks 18.1 -> see
+// profiles/r04_shard_balance_c5.txt)
+static std::vector<std::pair<int, int>> owner_ranges(const lrn_ctx* c, int lo, int hi, int piece) {
+  std::vector<std::pair<int, int>> out;
+  auto cut = [&](int a, int b) {
+    for (int x = a; x < b; x += piece) out.push_back({x, std::min(b, x + piece)});
+  };
+  if (c->world > 1) {
+    for (int c0 = (lo / c->shard_bs) * c->shard_bs; c0 < hi; c0 += c->shard_bs)
+      if (shard_owner(c0 / c->shard_bs, c->world) == c->rank) cut(std::max(lo, c0), std::min(hi, c0 + c->shard_bs));
+  } else {
+    cut(lo, hi);
+  }
+  return out;
+}
+
 static int assemble_sparse(lrn_ctx* c, LmiBlock& b) {
   const int n = c->nvar;
   double* H = c->H.as<double>();
   tic(c);
   if (b.q_wave > b.nd) {
-    int nown = b.q_wave - b.nd;
-    int noth = b.npos_nz - b.nd;
     // entries per wavefront by the typical product length: mean nnz of the sparse owners squared
     double mean_nnz = 0.0;
     for (int p = b.nd; p < b.npos_nz; ++p) mean_nnz += (double)b.nnz[p];
@@ -877,12 +894,12 @@ static int assemble_sparse(lrn_ctx* c, LmiBlock& b) {
     int lanes = c->opt.pair_lanes;
     if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 64) lanes = mean_nnz * mean_nnz <= 512.0 ? 16 : 64;
     const int per_wg = 256 / lanes;
-    for (int y0 = 0; y0 < nown; y0 += 32768) {
-      int ny = std::min(32768, nown - y0);
-      dim3 grid((noth - y0 + per_wg - 1) / per_wg, ny);
+    for (const auto& rg : owner_ranges(c, b.nd, b.q_wave, 2048)) {
+      const int a = rg.first, ny = rg.second - rg.first;
+      dim3 grid((b.npos_nz - a + per_wg - 1) / per_wg, ny);
 #define LRN_PAIR_LAUNCH(L)                                                                                           \
   hipLaunchKernelGGL(pair_wave_kernel<L>, grid, dim3(256), 0, c->stream, b.ent_ptr.as<long>(), b.ent_r.as<int>(),   \
-                     b.ent_c.as<int>(), b.ent_v.as<double>(), b.W.as<double>(), b.msz, b.nd + y0, b.q_wave,          \
+                     b.ent_c.as<int>(), b.ent_v.as<double>(), b.W.as<double>(), b.msz, a, rg.second,                \
                      b.npos_nz, b.hidx.as<int>(), H, n, c->rank, c->world, c->shard_bs)
       if (lanes == 4) LRN_PAIR_LAUNCH(4);
       else if (lanes == 8) LRN_PAIR_LAUNCH(8);
@@ -892,13 +909,12 @@ static int assemble_sparse(lrn_ctx* c, LmiBlock& b) {
     }
   }
   if (b.npos_nz > b.q_wave) {
-    int nown = b.npos_nz - b.q_wave;
-    for (int y0 = 0; y0 < nown; y0 += 32768) {
-      int ny = std::min(32768, nown - y0);
-      hipLaunchKernelGGL(pair_thread_kernel, dim3((nown - y0 + 255) / 256, ny), dim3(256), 0, c->stream,
+    for (const auto& rg : owner_ranges(c, b.q_wave, b.npos_nz, 4096)) {
+      const int a = rg.first, ny = rg.second - rg.first;
+      hipLaunchKernelGGL(pair_thread_kernel, dim3((b.npos_nz - a + 255) / 256, ny), dim3(256), 0, c->stream,
                          b.ent_ptr.as<long>(), b.ent_r.as<int>(), b.ent_c.as<int>(), b.ent_v.as<double>(),
-                         b.W.as<double>(), b.msz, b.q_wave + y0, b.npos_nz, b.hidx.as<int>(), H, n, c->rank,
-                         c->world, c->shard_bs);
+                         b.W.as<double>(), b.msz, a, b.npos_nz, b.hidx.as<int>(), H, n, c->rank,
+                         c->world, c->shard_bs);          // (owners a .. a + ny - 1 by the grid, partners up to npos_nz)
     }
   }
   toc(c, "sparse");
