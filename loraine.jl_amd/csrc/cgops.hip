@@ -866,7 +866,7 @@ static bool dense_stream_ok(const LmiBlock& b, const double* Z) {
   return !off && (b.msz & 1) == 0 && b.msz >= 256 && (((uintptr_t)Z | (uintptr_t)b.Adense.p) & 15) == 0;
 }
 
-static bool use_sparse_matvec(const lrn_ctx* c, const LmiBlock& b) {
+bool use_sparse_matvec(const lrn_ctx* c, const LmiBlock& b) {
   if (!b.sp_ok || c->opt.matvec_sparse == 1) return false;
   if (c->opt.matvec_sparse == 2) return true;
   // ~4e-12 ncq msz s against 4 msz^3 / 6e13 s.  Below msz ~ 1500 both routes are bound by their launches and L2: the

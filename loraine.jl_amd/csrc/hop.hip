@@ -233,12 +233,10 @@ static double est_operator_s(const lrn_ctx* c) {
   double t = 0.0;
   for (const auto& b : c->lmi) {
     const double m = b.msz;
-    if (b.sp_ok && c->opt.matvec_sparse != 1 &&
-        (c->opt.matvec_sparse == 2 || (b.msz < 1500 ? (b.msz >= 256 && (double)b.ncq * 12.0 < m * m && b.sp_long_cols.size() <= 4)
-                                                    : (double)b.ncq * 60.0 < m * m)))
+    if (use_sparse_matvec(c, b))
       t += (b.msz < 1500 ? 30e-6 : 10e-6) + (double)b.ncq * m * 1.43e-12;      // pattern route (C5: 2.58 ms, C3: 36 us)
     else
-      t += 4.0 * m * m * m / 5.0e13 + 2.0 * (double)b.nd * m * m * 8.0 / 5.5e12 + 40e-6;
+      t += 4.0 * m * m * m / 5.0e13 + (double)b.nd * m * m * 8.0 / 6.0e12 + 40e-6;      // two products + two passes over the column tails
   }
   return t;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "ctx.h"
 namespace lrn {
+bool use_sparse_matvec(const lrn_ctx* c, const LmiBlock& b);                // the pattern-restricted form of MyA serves this block
 int ensure_m(lrn_ctx* c, int m);                                            // c->m0..m2 >= msz^2
 int wmw(lrn_ctx* c, LmiBlock& b, double* M, double* P, double* Z);          // Z = W M W (M symmetric)
 int aa_times(lrn_ctx* c, LmiBlock& b, const double* Z, double* y);          // y += AA vec(Z)
