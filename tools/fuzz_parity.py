@@ -67,7 +67,10 @@ def main():
     # per-context options on the device every solve runs on: FUZZ_SCHUR_CHOL=1 takes the Cholesky-factor assembly paths regardless of size
     # (1: <L'A_iL, L'A_jL> where every constraint of a block is dense, T_k = L (L'A_kL) L' otherwise; 2: the latter
     # only), FUZZ_DENSE=1 stores every non-empty constraint matrix dense
-    if os.environ.get("FUZZ_SCHUR_CHOL") or os.environ.get("FUZZ_DENSE") or os.environ.get("FUZZ_STRICT"):
+    # FUZZ_LRN_OPTS=key=value,...: any per-context library option (round 4: matvec_h=2,prec_dense=2 send every kit=1 solve
+    # through the assembled Schur matrix and the dense H_alpha; lyap_form=0, ns_lanczos_min=8, wmw_pattern_min=2 ...)
+    if (os.environ.get("FUZZ_SCHUR_CHOL") or os.environ.get("FUZZ_DENSE") or os.environ.get("FUZZ_STRICT")
+            or os.environ.get("FUZZ_LRN_OPTS")):
         import loraine_jl_amd
         _d = loraine_jl_amd.Device(0)
         if os.environ.get("FUZZ_STRICT"):            # the literal reference behaviour on non-positive pivots
@@ -76,6 +79,9 @@ def main():
             _d.set_option("schur_chol", int(os.environ["FUZZ_SCHUR_CHOL"]))
         if os.environ.get("FUZZ_DENSE"):
             _d.set_option("dense_threshold", 1)
+        for kv in filter(None, os.environ.get("FUZZ_LRN_OPTS", "").split(",")):
+            k_, v_ = kv.split("=")
+            _d.set_option(k_, float(v_))
     for s in range(seed0, seed0 + count):
         rng = np.random.default_rng(s)
         A, b, d_lin, C_lin = random_problem(rng)
