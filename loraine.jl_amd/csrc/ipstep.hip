@@ -257,21 +257,32 @@ __device__ __forceinline__ void lz_fused_body(const double* __restrict__ M, int 
   }
   __syncthreads();
   if (!do_symv) return;
-  // rows [16 blockIdx.x, +16): thread (r, g) sums the columns g, g + 16, ...
-  const int r = t & 15, g = t >> 4;
-  const int i = blockIdx.x * 16 + r;
-  double acc = 0.0;
-  if (i < n) {
-    const double* mrow = M + i;
+  // rows [16 blockIdx.x, +16) of M q = the same COLUMNS of the symmetric M (contiguous): wave w takes four of them, its
+  // lanes run down the columns with the four loads of a step in flight together (round 4; round 3 walked the rows with a
+  // stride of n and four loads in flight per thread: 50 dependent rounds of L2 latency at msz 800)
+  {
+    const int lane = t & 63, w = t >> 6;
+    const int c0 = blockIdx.x * 16 + 4 * w;
+    const double* m0 = M + (size_t)min(c0 + 0, n - 1) * n;
+    const double* m1 = M + (size_t)min(c0 + 1, n - 1) * n;
+    const double* m2 = M + (size_t)min(c0 + 2, n - 1) * n;
+    const double* m3 = M + (size_t)min(c0 + 3, n - 1) * n;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 4
-    for (int col = g; col < n; col += 16) acc += mrow[(size_t)col * n] * qs[col];
+    for (int k = lane; k < n; k += 64) {
+      const double q = qs[k];
+      a0 += m0[k] * q; a1 += m1[k] * q; a2 += m2[k] * q; a3 += m3[k] * q;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64);
+      a2 += __shfl_down(a2, off, 64); a3 += __shfl_down(a3, off, 64);
+    }
+    if (lane == 0) { sh[4 * w + 0] = a0; sh[4 * w + 1] = a1; sh[4 * w + 2] = a2; sh[4 * w + 3] = a3; }
   }
-  sh[g * 16 + r] = acc;
   __syncthreads();
   if (t < 16) {
-    double y = 0.0;
-#pragma unroll
-    for (int gg = 0; gg < 16; ++gg) y += sh[gg * 16 + t];
+    const double y = sh[t];
     const int ii = blockIdx.x * 16 + t;
     double d = 0.0;
     if (ii < n) {
