@@ -781,6 +781,55 @@ int potrf_lower_boost(hipStream_t st, double* A, int n, int ld, double* Linv, do
                            hipMemcpyDeviceToDevice, st) != hipSuccess)
         return LRN_ERR_HIP;
     }
+    // Second blocking level (round 4; n >= 9000): above n ~ 6000 the step kernel is bound by the HBM traffic of the
+    // trailing matrix, which it re-streams for every 64 columns (n = 20 000: 333 GB, 100 ms at 26 TFLOP/s).  Super-blocks of
+    // SB = 1024 columns: inside one, a step updates only the super-block's own remaining columns (all rows below); the rest
+    // of the trailing matrix gets the sixteen panels at once, C -= L_sb L_sb' with K = 1024 on the 128-tile direct-to-LDS GEMM
+    // (a sixteenth of the traffic), and the next super-block starts like the factorisation itself (diagonal block + panel
+    // as launches of their own, the copy of tile (0, 0) for the replicas).
+    static const int sb_min = getenv("LRN_POTRF_SB_MIN") ? atoi(getenv("LRN_POTRF_SB_MIN")) : 9000;   // (6144: 5.1 -> 5.8 ms, slower; 10^4: 16.1 -> 14.8)
+    // (width sweep at n = 10^4 / 20 000: 256 -> 14.8 / 73.8 ms, 512 -> 13.1 / 61.9, 1024 -> 12.4 / 58.0; one level: 16.1 / 100)
+    static const int SB = getenv("LRN_POTRF_SB") ? std::max(2 * NB, (atoi(getenv("LRN_POTRF_SB")) / NB) * NB) : 16 * NB;
+    if (n >= sb_min && (ld & 1) == 0) {
+      for (int ks = 0; ks < n; ks += SB) {
+        if (ks > 0) {
+          // start of a super-block: its first diagonal block and panel (the trailing matrix is up to date: big update below)
+          const int remk = n - ks;
+          if (remk <= 0) break;
+          hipLaunchKernelGGL(potrf_diag_blk_kernel, dim3(1), dim3(256), 0, st, A + (long)ks + (long)ks * ld, ld,
+                             remk < NB ? remk : NB, ks, info_dev, diag0, boost, max_boost);
+          if (remk <= NB) break;
+          hipLaunchKernelGGL(potrf_panel_mfma_kernel, dim3((remk - NB + 63) / 64), dim3(256), 0, st,
+                             A + (long)(ks + NB) + (long)ks * ld, 1L, (long)ld, remk - NB, A + (long)ks + (long)ks * ld, ld, NB, 0,
+                             cur, 1L, (long)(remk - NB), info_dev);
+          const int e0 = remk - NB < NB ? remk - NB : NB;
+          if (hipMemcpy2DAsync(cur + t00_off, (size_t)NB * 8, A + (long)(ks + NB) + (long)(ks + NB) * ld, (size_t)ld * 8,
+                               (size_t)e0 * 8, e0, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return LRN_ERR_HIP;
+        }
+        const int ke = ks + SB < n ? ks + SB : n;                 // end of the super-block
+        for (int k0 = ks; k0 + NB < ke && n - k0 - NB > 0; k0 += NB) {
+          const int rem = n - k0 - NB;
+          const int nt = (rem + NB - 1) / NB;
+          const int ntj = (ke - k0 - NB + NB - 1) / NB;           // tile columns of the trailing matrix inside the super-block
+          double* nxt = (cur == work) ? Linv : work;
+          hipLaunchKernelGGL(potrf_step_kernel, dim3(nt, ntj < nt ? ntj : nt), dim3(256), 0, st,
+                             A + (long)(k0 + NB) + (long)(k0 + NB) * ld, ld, rem, cur, nxt, cur + t00_off, nxt + t00_off,
+                             info_dev, k0 + NB, diag0, boost, max_boost);
+          cur = nxt;
+        }
+        if (ke >= n) break;
+        GemmDesc u;                                               // A[ke:, ke:] -= L[ke:, ks:ke] L[ke:, ks:ke]'  (lower tiles)
+        u.A = A + (long)ke + (long)ks * ld; u.sAm = 1; u.sAk = ld;
+        u.B = A + (long)ke + (long)ks * ld; u.sBk = ld; u.sBn = 1;
+        u.C = A + (long)ke + (long)ke * ld; u.sCm = 1; u.sCn = ld;
+        u.M = n - ke; u.N = n - ke; u.K = ke - ks;
+        u.alpha = -1.0; u.beta = 1.0; u.flags = GEMM_TRI_LOWER;
+        const int rcg = gemm(st, u);
+        if (rcg) return rcg;
+      }
+      return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+    }
     for (int k0 = 0; n - k0 - NB > 0; k0 += NB) {
       const int rem = n - k0 - NB;
       const int nt = (rem + NB - 1) / NB;

@@ -146,6 +146,29 @@ def test_potrs_superblock_path(dev, n):
     assert relerr(A @ x, b) < 1e-10
 
 
+@pytest.mark.parametrize("n", [9216, 9500, 10040])
+def test_potrf_two_level_blocking(dev, n):
+    """n >= 9000: super-blocks of 1024 columns -- inside one the steps update only its own remaining columns, the rest of
+    the trailing matrix gets the sixteen panels at once (K = 1024 GEMM on the lower tiles), the next super-block starts with
+    a diagonal-block and a panel launch of its own (round 4, chol.hip).  9216 = 9 x 1024; 9500 and 10040: ragged last
+    super-block / last 64-block; a failing pivot in the second super-block is reported at its column."""
+    rng = np.random.default_rng(n)
+    Mx = rng.standard_normal((n, 64))
+    d = 1.0 + rng.random(n)
+    A = Mx @ Mx.T + np.diag(d) * 8.0                     # SPD, cond ~ 1e2
+    L, info = dev.dbg_potrf(A)
+    assert info == 0
+    L = np.tril(L)
+    assert np.abs(L @ L.T - A).max() <= 1e-13 * np.abs(A).max() * 64
+    Lref = np.linalg.cholesky(A)
+    assert relerr(L, Lref) < 1e-12
+    bad = 1024 + 70                                       # second panel of the second super-block
+    B = A.copy()
+    B[bad, bad] = -1.0
+    _, info = dev.dbg_potrf(B)
+    assert info == bad + 1
+
+
 def test_potrf_reports_not_pd(dev):
     rng = np.random.default_rng(3)
     n = 200
