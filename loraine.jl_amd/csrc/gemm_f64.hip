@@ -342,8 +342,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   // K-step, the blocks a triangular operand leaves zero) is shared evenly by the four waves: a tile costs its
   // busiest wave.  Bit i * 4 + j of a mask = block (i, j) of this wave; masks are wave-uniform (SGPR).
   unsigned smask = 0;
+  unsigned zmask = 0;        // blocks that are not computed but stored (as zeros): GEMM_DIAG_LOWER_Z
   {
     const bool diag_pk = EPI && (d.flags & GEMM_C_PACKED) && tm == tn;   // stored: blocks with bn >= bm only
+    const bool diag_lz = (d.flags & GEMM_DIAG_LOWER_Z) && tm == tn;      // computed: blocks with bm >= bn only
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -351,6 +353,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
         const int bm = 2 * i + wm, bn = 2 * j + wn;
         bool need = (m0 + 16 * bm < d.M) && (n0 + 16 * bn < d.N);
         if (diag_pk && bn < bm) need = false;
+        if (diag_lz && bm < bn && !(d.flags & GEMM_NO_SKIP)) {
+          if (need) zmask |= 1u << (i * 4 + j);
+          need = false;
+        }
         if (d.flags & GEMM_NO_SKIP) need = true;
         if (need) smask |= 1u << (i * 4 + j);
       }
@@ -496,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     //  * a tile with skipped blocks (edge, packed diagonal tile): the smallest pattern that contains its blocks, for all
     //    its K-steps (a block of the head computed too early multiplies stored zeros);
     //  * the K-steps of a KTO tail run unmasked (stored zeros again).
-    int e[10];                                    // end of the K-steps of pattern q (see the loops below)
+    int e[12];                                    // end of the K-steps of pattern q (see the loops below)
 #pragma unroll
-    for (int q = 0; q < 10; ++q) e[q] = kt0;
+    for (int q = 0; q < 12; ++q) e[q] = kt0;
     if (smask == 0xffffu) {
       if ((from_n | from_m) && !(d.flags & GEMM_NO_SKIP)) {
         const int w0 = kt0 + (from_n ? wn : wm);
@@ -511,9 +517,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
       if ((smask & ~0x1111u) == 0u) e[1] = nk;
       else if ((smask & ~0x000fu) == 0u) e[4] = nk;
       else if ((smask & ~0x08ceu) == 0u) e[7] = nk;
+      else if ((smask & ~0x7310u) == 0u) e[9] = nk;
       else if ((smask & ~0x3333u) == 0u) e[2] = nk;
       else if ((smask & ~0x00ffu) == 0u) e[5] = nk;
       else if ((smask & ~0x8cefu) == 0u) e[8] = nk;
+      else if ((smask & ~0xf731u) == 0u) e[10] = nk;
       else if ((smask & ~0x7777u) == 0u) e[3] = nk;
       else if ((smask & ~0x0fffu) == 0u) e[6] = nk;
     }
@@ -526,6 +534,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     LRN_PATTERN_LOOP(1, 0x1111u) LRN_PATTERN_LOOP(2, 0x3333u) LRN_PATTERN_LOOP(3, 0x7777u)     // block columns 0 .. NJ-1 of the wave
     LRN_PATTERN_LOOP(4, 0x000fu) LRN_PATTERN_LOOP(5, 0x00ffu) LRN_PATTERN_LOOP(6, 0x0fffu)     // block rows 0 .. NI-1
     LRN_PATTERN_LOOP(7, 0x08ceu) LRN_PATTERN_LOOP(8, 0x8cefu)                                   // packed diagonal tile: bn > bm, bn >= bm
+    LRN_PATTERN_LOOP(9, 0x7310u) LRN_PATTERN_LOOP(10, 0xf731u)                                  // GEMM_DIAG_LOWER_Z: bm > bn, bm >= bn
 #undef LRN_PATTERN_LOOP
     for (; kt < nk; ++kt) fast_step(kt);
   }
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if (!(smask & (1u << (i * 4 + j)))) continue;
+      if (!((smask | zmask) & (1u << (i * 4 + j)))) continue;      // (zmask: the accumulators were never touched -- zeros)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int m = m0 + (2 * i + wm) * 16 + MFMA_F64_ROW(lane, r);
@@ -1020,6 +1029,7 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     else if (d.flags & GEMM_TRI_UPPER) d.flags = (d.flags & ~GEMM_TRI_UPPER) | GEMM_TRI_LOWER;
     if (d.flags & GEMM_DIAG_LOWER) d.flags = (d.flags & ~GEMM_DIAG_LOWER) | GEMM_DIAG_UPPER;
     else if (d.flags & GEMM_DIAG_UPPER) d.flags = (d.flags & ~GEMM_DIAG_UPPER) | GEMM_DIAG_LOWER;
+    d.flags &= ~GEMM_DIAG_LOWER_Z;                 // (a hint for the unswapped orientation only)
   }
   const bool tri = d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER);
   const bool kflat = d.flags & GEMM_KFLAT;

@@ -64,6 +64,9 @@ enum : int {
   GEMM_DYN_MASKS = 131072, // measurement only (option "gemm_dyn_masks"): no straight-line K-steps for the common block
                            // patterns, every masked K-step branches per block (the round-2 kernel)
   GEMM_NO_SKIP = 32768,    // measurement only (option "gemm_no_skip"): compute every block of every tile
+  GEMM_DIAG_LOWER_Z = 262144, // direct-to-LDS kernel (GEMM1'): in diagonal tiles the 16x16 blocks above the block diagonal
+                           // (m / 16 < n / 16) are not computed and STORED AS ZEROS (the caller multiplies them by zeros:
+                           // stale NaNs must not be left there); a hint -- any other kernel computes them
   GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower layout;
                            // the first kflat_nsd splits cover the diagonal blocks [0, kflat_diag), the
                            // others the strictly-lower blocks [kflat_diag, K)

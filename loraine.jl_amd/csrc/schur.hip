@@ -519,8 +519,10 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g1.B = Ut + off; g1.sBk = m; g1.sBn = 1; g1.bB = 0;     // op(B)[k][j] = L[k,j] = Ut[j + k*m]
       g1.C = P; g1.sCm = ldp; g1.sCn = 1; g1.bC = p_elems;
       g1.M = g1.K = m - c0; g1.N = c1 - c0; g1.batch = nb;
+      // (round 4: of the diagonal tiles of P_k GEMM2' reads only the blocks on and below the block diagonal -- the
+      // others meet the stored zeros of L' -- so GEMM1' leaves them out: 28 of 64 blocks of the 16 longest tiles)
       g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
-                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0);
+                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0) | (c->opt.gemm1_diag ? GEMM_DIAG_LOWER_Z : 0);
       LRN_TRY(gemm(c->stream, g1));
       toc(c, "gemm1");
       tic(c);

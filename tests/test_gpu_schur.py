@@ -601,6 +601,33 @@ def test_gemm12_pattern_loops_equal_the_branch_per_block_kernel(dev, msz):
     assert relerr(Hs[0][:6, :6], np.tril(_brute_H(A, W))) < 1e-13
 
 
+@pytest.mark.parametrize("msz", [200, 300, 457, 1000])
+def test_gemm1_leaves_out_the_blocks_gemm2_never_reads(dev, msz):
+    """Round 4: in the diagonal tiles of P_k = A_k L the 16x16 blocks above the block diagonal are read by GEMM2' only
+    against the stored zeros of L' -- GEMM1' does not compute them and stores zeros (option gemm1_diag, default 1; pattern
+    loops and the branch-per-block body).  Bit-identical to computing them, twice in a row (the zeros are re-stored: the
+    workspace holds the full products of the gemm1_diag = 0 run in between), and equal to the definition."""
+    nvar = 70
+    dev.synthetic_dense_model(msz, nvar, 47)
+    W, G = _spd(msz, 48)
+    dev.set_scaling(0, W, G)
+    dev.set_option("schur_chol", 1)
+    Hs = []
+    try:
+        for diag, dyn in ((1, 0), (0, 0), (1, 0), (1, 1)):
+            dev.set_option("gemm1_diag", diag)
+            dev.set_option("gemm_dyn_masks", dyn)
+            Hs.append(np.tril(dev.schur_assemble(0, want_H=True)))
+    finally:
+        dev.set_option("gemm1_diag", 1)
+        dev.set_option("gemm_dyn_masks", 0)
+        dev.set_option("schur_chol", -1)
+    for H in Hs[1:]:
+        assert np.array_equal(Hs[0], H)
+    A = np.stack([dev.get_constraint(0, k) for k in range(6)])
+    assert relerr(Hs[0][:6, :6], np.tril(_brute_H(A, W))) < 1e-13
+
+
 @pytest.mark.parametrize("nvar", [416, 1050, 1056])
 def test_gemm3_last_tile_row_of_height_160(dev, nvar):
     """nvar % 128 in (0, 32]: the last 128 + nvar % 128 rows of H are tiled by 128 x 160 and one 160 x 160 tile on a second
