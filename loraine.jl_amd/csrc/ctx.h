@@ -82,6 +82,8 @@ struct LrnOptions {
                                   // Schur column blocks, 1 all-reduce of partial sums); see lrn_schur_plan
   int gemm3_ksplit = 0;           // split-K factor of GEMM3 / GEMM3' (0 = auto)
   int gemm_dyn_masks = 0;         // measurement only: GEMM_DYN_MASKS on GEMM1'/2'
+  int gemm_lab = 0;               // measurement only: GEMM_LAB_* bits (<< 20) on GEMM1'/2'; bit 4: every tile walks the whole K
+                                  // range (tools/gemm12_overhead.py)
   int gemm1_diag = 1;             // GEMM1': diagonal tiles compute only the blocks GEMM2' reads (GEMM_DIAG_LOWER_Z); 0: all
   int gemm_no_skip = 0;           // measurement only: GEMM1'/2'/3' compute every 16x16 block (GEMM_NO_SKIP)
   int gemm3_sched = 1;            // 1: one launch, regular tiles of every split first, short tiles last; 0: two launches

@@ -475,9 +475,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     }
     __syncthreads();
   };
-  issue(kt0, kt0 & 1);
+  if (!(d.flags & GEMM_LAB_NO_LOAD)) issue(kt0, kt0 & 1);
   __syncthreads();
-  int kt = kt0;
+  int kt = (d.flags & GEMM_LAB_NO_KLOOP) ? nk : kt0;
   if constexpr (DYN) {
     int head_end = kt0, tail_begin = nk;          // K-steps [kt0, head_end) and [tail_begin, nk) run block by block
     if (smask != 0xffffu) {
@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     for (; kt < nk; ++kt) fast_step(kt);
   }
   LRN_MFMA_DRAIN();
+  if (d.flags & GEMM_LAB_NO_STORE) return;
 
   const bool x2 = EPI && (d.flags & GEMM_OFFDIAG_X2) && (tm != tn);
   const double alpha = x2 ? 2.0 * d.alpha : d.alpha;
@@ -1196,12 +1197,17 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (!small && !kseg && lds_path_ok(d)) {
+    const unsigned dyn = (d.flags & GEMM_LAB_ONE_WG) ? 24576u : 0u;        // (measurement only)
+    if (dyn) {
+      (void)hipFuncSetAttribute((const void*)gemm_f64_lds_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      (void)hipFuncSetAttribute((const void*)gemm_f64_lds_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    }
     if (d.flags & GEMM_DYN_MASKS) {
       if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true, true>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((gemm_f64_lds_kernel<false, true>), grid, dim3(256), 0, st, p);
     } else {
-      if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true, false>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_f64_lds_kernel<false, false>), grid, dim3(256), 0, st, p);
+      if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true, false>), grid, dim3(256), dyn, st, p);
+      else hipLaunchKernelGGL((gemm_f64_lds_kernel<false, false>), grid, dim3(256), dyn, st, p);
     }
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }

@@ -67,6 +67,11 @@ enum : int {
   GEMM_DIAG_LOWER_Z = 262144, // direct-to-LDS kernel (GEMM1'): in diagonal tiles the 16x16 blocks above the block diagonal
                            // (m / 16 < n / 16) are not computed and STORED AS ZEROS (the caller multiplies them by zeros:
                            // stale NaNs must not be left there); a hint -- any other kernel computes them
+  GEMM_LAB_NO_STORE = 1 << 20,  // measurement only (option "gemm_lab", tools/gemm12_overhead.py): direct-to-LDS kernel without
+                                // its epilogue
+  GEMM_LAB_NO_KLOOP = 1 << 21,  // ... without its K loop (the first K-step is still loaded and waited for)
+  GEMM_LAB_NO_LOAD = 1 << 22,   // ... without the first load either (with the two above: an empty workgroup)
+  GEMM_LAB_ONE_WG = 1 << 23,    // ... launched with 24 KB of unused dynamic LDS: one workgroup per CU instead of two
   GEMM_KFLAT = 512,        // both operands K-contiguous, K = flat index of the packed lower layout;
                            // the first kflat_nsd splits cover the diagonal blocks [0, kflat_diag), the
                            // others the strictly-lower blocks [kflat_diag, K)

@@ -522,7 +522,9 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       // (round 4: of the diagonal tiles of P_k GEMM2' reads only the blocks on and below the block diagonal -- the
       // others meet the stored zeros of L' -- so GEMM1' leaves them out: 28 of 64 blocks of the 16 longest tiles)
       g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
-                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0) | (c->opt.gemm1_diag ? GEMM_DIAG_LOWER_Z : 0);
+                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0) | (c->opt.gemm1_diag ? GEMM_DIAG_LOWER_Z : 0) |
+                 ((c->opt.gemm_lab & 15) << 20);
+      if (c->opt.gemm_lab & 16) g1.flags &= ~GEMM_KFROM_N;      // (measurement: every tile walks the whole K range -- stored zeros)
       LRN_TRY(gemm(c->stream, g1));
       toc(c, "gemm1");
       tic(c);
@@ -533,7 +535,8 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g2.pk_cstride = cstride;
       g2.M = g2.K = m - c0; g2.N = c1 - c0; g2.batch = nb;
       g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
-                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0);
+                 (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0) | ((c->opt.gemm_lab & 15) << 20);
+      if (c->opt.gemm_lab & 16) g2.flags &= ~GEMM_KFROM_M;
       g2.pk_m = m;
       g2.pk_off = c0;
       LRN_TRY(gemm(c->stream, g2));
