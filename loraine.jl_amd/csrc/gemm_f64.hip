@@ -869,12 +869,12 @@ static bool lds_path_ok(const GemmDesc& d) {
 // equally long and advance in lock-step through K (that is where its L2 hits come from); shorter workgroups mixed in
 // break the step -- measured at C4: 496 -> 520 ms although 7 % of the MFMAs were skipped.
 static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count, int short_sel = 0, bool edge_m = false,
-                                 bool edge_n = false, bool diag = false) {
+                                 bool edge_n = false, bool diag = false, int korder = 0) {
   struct Key {
     int a, b, c;
     bool operator<(const Key& o) const { return a != o.a ? a < o.a : (b != o.b ? b < o.b : c < o.c); }
   };
-  tri |= short_sel << 8 | (edge_m ? 1 << 12 : 0) | (edge_n ? 1 << 13 : 0) | (diag ? 1 << 14 : 0);
+  tri |= short_sel << 8 | (edge_m ? 1 << 12 : 0) | (edge_n ? 1 << 13 : 0) | (diag ? 1 << 14 : 0) | korder << 16;
   struct Val { int2* dev; int n; };
   static std::map<Key, Val> cache[16];
   static std::mutex mu;                       // contexts on several host threads share the cache
@@ -897,6 +897,17 @@ static const int2* get_tile_list(int tilesM, int tilesN, int tri, int* count, in
           if ((short_sel == 1 && shrt) || (short_sel == 2 && !shrt)) continue;
           v.push_back(make_int2(tm, tn));
         }
+  if (korder) {
+    // (measurement, LRN_TILE_ORDER: the tiles of a triangular-K product by K length -- korder 1 / 2: K grows with tn / tm
+    // downwards -- longest, shortest, second longest, second shortest, ...)
+    std::vector<int2> srt = v, mix;
+    std::stable_sort(srt.begin(), srt.end(), [&](const int2& a, const int2& b) { return korder == 1 ? a.y < b.y : a.x < b.x; });
+    for (size_t i = 0, j = srt.size(); i < j;) {
+      mix.push_back(srt[i++]);
+      if (i < j) mix.push_back(srt[--j]);
+    }
+    v.swap(mix);
+  }
   if (short_sel == 2 && diag) {
     // every XCD walks one contiguous run of the list: deal the diagonal tiles (10 of 16 blocks per wave) and the
     // edge tiles (a quarter of the rows) alternately, so that the runs are equally long
@@ -1171,9 +1182,11 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     }
     return hipGetLastError() == hipSuccess ? LRN_OK : gemm_fail(LRN_ERR_HIP, "gemm: launch failed");
   }
+  static const int tile_order = getenv("LRN_TILE_ORDER") ? atoi(getenv("LRN_TILE_ORDER")) : 0;      // (measurement knob)
+  const int korder = (tile_order && d.tile_class == 0 && d.batch > 1) ? ((d.flags & GEMM_KFROM_N) ? 1 : (d.flags & GEMM_KFROM_M) ? 2 : 0) : 0;
   p.tile_list = get_tile_list(p.tilesM, p.tilesN, d.flags & (GEMM_TRI_LOWER | GEMM_TRI_UPPER), &ntile, d.tile_class,
                               d.tile_class != 0 && (d.M % BMv) != 0, d.tile_class != 0 && (d.N % BMv) != 0,
-                              d.tile_class != 0 && (d.flags & (GEMM_DIAG_LOWER | GEMM_DIAG_UPPER)) != 0);
+                              d.tile_class != 0 && (d.flags & (GEMM_DIAG_LOWER | GEMM_DIAG_UPPER)) != 0, korder);
   if (d.tile_class != 0 && p.tile_list && ntile == 0) return LRN_OK;      // nothing of that class
   if (!p.tile_list || ntile <= 0) return gemm_fail(LRN_ERR_NOMEM, "gemm: tile list allocation failed");
   (void)tri;

@@ -524,6 +524,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g1.flags = GEMM_TRI_LOWER | GEMM_KFROM_N | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
                  (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0) | (c->opt.gemm1_diag ? GEMM_DIAG_LOWER_Z : 0) |
                  ((c->opt.gemm_lab & 15) << 20);
+      if (c->opt.gemm_lab & 32) g1.bA = 0;                       // (measurement: every batch element reads matrix 0 -- cache-resident)
       if (c->opt.gemm_lab & 16) g1.flags &= ~GEMM_KFROM_N;      // (measurement: every tile walks the whole K range -- stored zeros)
       LRN_TRY(gemm(c->stream, g1));
       toc(c, "gemm1");
@@ -536,6 +537,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g2.M = g2.K = m - c0; g2.N = c1 - c0; g2.batch = nb;
       g2.flags = GEMM_TRI_LOWER | GEMM_KFROM_M | GEMM_C_PACKED | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
                  (c->opt.gemm_dyn_masks ? GEMM_DYN_MASKS : 0) | ((c->opt.gemm_lab & 15) << 20);
+      if (c->opt.gemm_lab & 32) g2.bB = 0;
       if (c->opt.gemm_lab & 16) g2.flags &= ~GEMM_KFROM_M;
       g2.pk_m = m;
       g2.pk_off = c0;
