@@ -609,6 +609,139 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_lds_kernel(GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------ mid-size products (round 4)
+// One plain product whose 64 x 64 tiles do not fill the chip by themselves (msz 400 .. 1400: Newton-Schulz, the Lyapunov CG
+// and the step-length products of C2 / C3, 70-90 per IP iteration): split-K over 2-4 workgroups per tile, slabs added by
+// reduce_slabs.  On the register-staged kernel above (one K-tile of global loads in flight per workgroup) the product
+// 801^3 took 33.5 us with the MFMA pipe 37 % busy -- every K-tile waits a global-load latency.  Here the operand panels go
+// global -> LDS by DMA into FOUR LDS stages: the panels of K-tile t + 3 are requested before the MFMAs of K-tile t, one
+// barrier per K-tile, the wait counts set by hand (s_waitcnt vmcnt(8): the DMA instructions of the two stages after this
+// one may still be in flight).  16-byte DMA (`buffer_load_dwordx4 ... lds`) from rows that are only 8-byte aligned
+// (msz = 801): measured correct on gfx950 (tools/probe_unaligned_dma.py; the first version of this kernel moved 4 bytes
+// per lane and was bound by its 64 DMA instructions per K-tile: 41.5 us).  One DMA instruction fills two k-rows of the
+// unpadded [k][64] image (lanes 0-31 / 32-63); the bank conflicts of the fragment reads are removed by an XOR of the 16-byte
+// unit index with 8 (k & 3), applied to the source address and to the read.  Both operands contiguous along their non-K
+// dimension, C contiguous along the kernel's n; 64 x 64 tile, 4 waves 2 x 2, 64 KB of LDS: two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void gemm_f64_mid_kernel(GemmParams p) {
+  constexpr int BM = 64, BN = 64, NST = 3;
+  constexpr int LA = BK * BM;                   // doubles per image
+  __shared__ double lds[NST * 2 * LA];
+  const GemmDesc& d = p.d;
+  // 1-D grid, a multiple of 8 workgroups: XCD x = blockIdx.x % 8 takes the items [x q, (x + 1) q) of the (tile, split) list
+  // (tile-major: the splits of a tile and the tiles that share panels stay in one L2); p.n1 = tiles x splits items.  No
+  // workgroup that exits at once sits in the middle of the grid: the dispatcher then fills the CUs evenly (with a (tiles
+  // padded to 8) x splits grid 14 CUs received three workgroups and 19 one: 29 us instead of 21)
+  int tm, tn, ks;
+  {
+    const int q = gridDim.x >> 3;
+    const int item = (blockIdx.x & 7) * q + (blockIdx.x >> 3);
+    if (item >= p.n1) return;
+    const int2 tt = p.tile_list[item / d.ksplit];
+    tm = tt.x;
+    tn = tt.y;
+    ks = item % d.ksplit;
+  }
+  const int t = threadIdx.x, lane = t & 63;
+  unsigned long long* trace = d.lab_trace ? d.lab_trace + 8 * ((long)blockIdx.x + (long)gridDim.x * blockIdx.z) : nullptr;
+  if (trace && t == 0) {
+    trace[0] = wall_clock64();
+    trace[1] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+  }
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w & 1, wn = w >> 1;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lda = (int)d.sAk, ldb = (int)d.sBk;
+  const unsigned bytesA = (unsigned)(((long)(d.K - 1) * lda + d.M) * 8);
+  const unsigned bytesB = (unsigned)(((long)(d.K - 1) * ldb + d.N) * 8);
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)d.A, 0, bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)d.B, 0, bytesB, 0x00020000);
+  // DMA instruction jj (0, 1) of this wave and stage fills the k-rows 2 (w + 4 jj) + (lane >> 5); lane & 31 is the 16-byte
+  // unit of the LDS row, unit ^ 8 (k & 3) the unit of the source row ((2 w + (lane >> 5)) & 3 = k & 3 for both jj)
+  const int krow = 2 * w + (lane >> 5);
+  const int usrc = (lane & 31) ^ (8 * (krow & 3));
+  const int ma = m0 + 2 * usrc, nb = n0 + 2 * usrc;
+  const unsigned offA = ma < d.M ? (unsigned)ma * 8u : 0x80000000u;
+  const unsigned offB = nb < d.N ? (unsigned)nb * 8u : 0x80000000u;
+  const int k_lo = ks * p.kchunk;
+  int k_hi = k_lo + p.kchunk;
+  if (k_hi > d.K) k_hi = d.K;
+  const int nkt = k_hi > k_lo ? (k_hi - k_lo + BK - 1) / BK : 0;
+  // K-tile `it` of this split -> stage buf.  k-rows at or beyond k_hi belong to the next split (or lie beyond K): their
+  // offsets are sent out of range -- zero fill.
+  auto issue = [&](int it, int buf) {
+    double* sa = lds + buf * (2 * LA);
+    double* sb = sa + LA;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int k = k_lo + it * BK + 8 * jj + krow;
+      const unsigned oob = k < k_hi ? 0u : 0x80000000u;
+      const unsigned ka = (unsigned)k * (unsigned)lda * 8u, kb = (unsigned)k * (unsigned)ldb * 8u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + (2 * w + 8 * jj) * BM), 16,
+                                               (int)((offA + ka) | oob), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + (2 * w + 8 * jj) * BN), 16,
+                                               (int)((offB + kb) | oob), 0, 0, 0);
+    }
+  };
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  const int fr = lane & 15, fk = lane >> 4;
+  // fragment (k = 4 kk + fk, m = 16 b + fr) of an image: row k, unit ((m >> 1) ^ 8 (k & 3)) = doubles ((16 b) ^ (16 fk)) + fr
+  int fa_off[2], fb_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    fa_off[i] = fk * BM + (((wm * 32 + i * 16)) ^ (16 * fk)) + fr;
+    fb_off[i] = fk * BN + (((wn * 32 + i * 16)) ^ (16 * fk)) + fr;
+  }
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nkt) issue(s0, s0);
+  for (int it = 0; it < nkt; ++it) {
+    // stage `it` has landed (this wave's part; the barrier extends that to the workgroup) -- the 4 DMA instructions of each
+    // of the stages it + 1, it + 2, issued after it, may still be in flight
+    if (NST == 4 && it + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (it + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (trace && t == 0 && it < 4) trace[2 + it] = wall_clock64();
+    // every wave is past the MFMAs of K-tile it - 1: its stage is free for K-tile it + 3
+    if (it + NST - 1 < nkt) issue(it + NST - 1, (it + NST - 1) % NST);
+    const double* sa = lds + (it % NST) * (2 * LA);
+    const double* sb = sa + LA;
+    double fa[BK / 4][2], fb[BK / 4][2];
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[kk][i] = sa[kk * 4 * BM + fa_off[i]];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[kk][j] = sb[kk * 4 * BN + fb_off[j]];
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+  }
+  if (trace && t == 0) trace[6] = wall_clock64();
+  double* __restrict__ Cg = d.C + (long)ks * d.sCs;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + MFMA_F64_ROW(lane, r);
+        const int n = n0 + wn * 32 + j * 16 + fr;
+        if (m < d.M && n < d.N) Cg[(long)m * d.sCm + n] = d.alpha * acc[i][j][r];
+      }
+  if (trace && t == 0) trace[7] = wall_clock64();
+}
+
 // ------------------------------------------------------------------ direct-to-LDS, K-contiguous
 // GEMM3 of the Schur assembly: H[i,j] = <A_i, T_j>, both operands contiguous along K (the vec
 // index of an msz x msz matrix), K walked in the lower-tile segments of GEMM_KSEG_TRI.
@@ -850,8 +983,9 @@ static bool kseg_lds_path_ok(const GemmDesc& d) {
 
 static bool lds_path_ok(const GemmDesc& d) {
   if (d.sAm != 1 || d.sBn != 1 || d.ksplit != 1) return false;
-  if (d.sAk < d.M || d.sBk < d.N || (d.sAk & 1) || (d.sBk & 1)) return false;
-  if (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || (d.bA & 1) || (d.bB & 1)) return false;
+  static const bool unaligned = getenv("LRN_LDS_UNALIGNED") != nullptr;       // (hardware probe: 16-byte DMA from 8-byte aligned rows)
+  if (d.sAk < d.M || d.sBk < d.N || (!unaligned && ((d.sAk & 1) || (d.sBk & 1)))) return false;
+  if (!unaligned && (((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || (d.bA & 1) || (d.bB & 1))) return false;
   // short-K products (Cholesky panel / trailing updates) stay on the generic kernel: the DMA
   // pipeline needs a long K loop to pay off, and it keeps this kernel's profile = the assembly GEMMs
   if (d.K < 256) return false;
@@ -991,6 +1125,7 @@ static int auto_split_factor(const GemmDesc& d) {
   if (ks < 2) ks = 2;
   if (ks > 4) ks = 4;
   while (ks > 2 && d.K / ks < 128) --ks;
+  while (ks > 2 && t64 * ks > 512) --ks;                       // (gemm_f64_mid_kernel: two workgroups per CU, all resident)
   return (int)ks;
 }
 
@@ -1210,6 +1345,7 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (!small && !kseg && lds_path_ok(d)) {
+    if (getenv("LRN_LDS_UNALIGNED") && ((d.sAk & 1) || (d.sBk & 1))) fprintf(stderr, "[gemm] direct-to-LDS kernel on odd leading dimensions %ld %ld\n", d.sAk, d.sBk);
     const unsigned dyn = (d.flags & GEMM_LAB_ONE_WG) ? 24576u : 0u;        // (measurement only)
     if (dyn) {
       (void)hipFuncSetAttribute((const void*)gemm_f64_lds_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
@@ -1221,6 +1357,31 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     } else {
       if (epi) hipLaunchKernelGGL((gemm_f64_lds_kernel<true, false>), grid, dim3(256), dyn, st, p);
       else hipLaunchKernelGGL((gemm_f64_lds_kernel<false, false>), grid, dim3(256), dyn, st, p);
+    }
+    return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+  }
+  static const int mid_off = getenv("LRN_GEMM_MID") ? (atoi(getenv("LRN_GEMM_MID")) == 0) : 0;      // (measurement knob)
+  if (small && !mid_off && !kseg && !epi && d.batch == 1 && d.ksplit > 1 && d.beta == 0.0 && d.sAm == 1 && d.sBn == 1 &&
+      d.sCn == 1 && d.sAk >= d.M && d.sBk >= d.N && !(d.flags & ~GEMM_SMALL_TILE) &&
+      (double)d.K * (double)std::max(d.sAk, d.sBk) * 8.0 < 2.0e9) {
+    // the split-K slabs of a mid-size product (gemm() below): four-stage LDS DMA pipeline
+    static const char* trace_path = getenv("LRN_MID_TRACE");       // (measurement: clocks of the workgroups of launch #40)
+    static int trace_launch = 0;
+    unsigned long long* tb = nullptr;
+    p.n1 = p.tilesM * p.tilesN * d.ksplit;                        // (flags == 0: every tile of the grid, real entries first in the list)
+    grid = dim3((unsigned)((p.n1 + 7) & ~7), 1, 1);
+    const size_t tw = 8 * (size_t)grid.x * grid.z;
+    if (trace_path && ++trace_launch == 40 && hipMalloc(&tb, tw * 8) == hipSuccess) {
+      (void)hipMemsetAsync(tb, 0, tw * 8, st);
+      p.d.lab_trace = tb;
+    }
+    hipLaunchKernelGGL(gemm_f64_mid_kernel, grid, dim3(256), 0, st, p);
+    if (tb) {
+      std::vector<unsigned long long> h(tw);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h.data(), tb, tw * 8, hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, tw, f); fclose(f); }
+      (void)hipFree(tb);
     }
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }

@@ -138,6 +138,7 @@ struct GemmDesc {
                            // launch, class 1 of every split first, class 2 last
   // tile_class 4 / 5 (GEMM_KFLAT, M == N, M % 128 in (0, 32]): 4 = as 3 for the leading M - 128 - M % 128 rows; 5 = the last
   // 128 + M % 128 rows tiled by 128 x 160
+  unsigned long long* lab_trace = nullptr;   // measurement only (LRN_MID_TRACE): 8 words per workgroup, clocks of its phases
   int kstagger = 0;        // GEMM_KFLAT: workgroup (tm, tn) starts its K walk ((tm + tn) & 7) * kstagger chunks into
                            // its split and wraps around (see gemm_f64_kseg_lds_kernel)
 };
