@@ -1129,7 +1129,7 @@ static int auto_split_factor(const GemmDesc& d) {
   return (int)ks;
 }
 
-int gemm(hipStream_t st, const GemmDesc& din) {
+static int gemm_maybe_slabs(hipStream_t st, const GemmDesc& din, SlabSrc* out) {
   tls_gemm_error = nullptr;            // (a stale reason must not be appended to a later, unrelated error)
   const int ks = auto_split_factor(din);
   if (ks > 1) {
@@ -1141,13 +1141,22 @@ int gemm(hipStream_t st, const GemmDesc& din) {
       d2.flags |= GEMM_SMALL_TILE;
       const int rc2 = gemm_impl(st, d2);
       if (rc2 != LRN_OK) { if (!tls_gemm_error) tls_gemm_error = "kernel launch failed"; return rc2; }
+      if (out && din.beta == 0.0) {
+        out->p = slabs; out->stride = (long)mn; out->n = ks;
+        return LRN_OK;
+      }
+      if (out) { out->p = din.C; out->stride = 0; out->n = 1; }
       return reduce_slabs(st, slabs, (long)mn, ks, din.C, (long)mn, din.beta);
     }
   }
+  if (out) { out->p = din.C; out->stride = 0; out->n = 1; }
   const int rc = gemm_impl(st, din);
   if (rc != LRN_OK && !tls_gemm_error) tls_gemm_error = "kernel launch failed";
   return rc;
 }
+
+int gemm(hipStream_t st, const GemmDesc& din) { return gemm_maybe_slabs(st, din, nullptr); }
+int gemm_slabs(hipStream_t st, const GemmDesc& din, SlabSrc* out) { return gemm_maybe_slabs(st, din, out); }
 
 static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   GemmParams p;

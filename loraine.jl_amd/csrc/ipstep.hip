@@ -769,7 +769,7 @@ static int eigmin_certify(lrn_ctx* c, const double* M, int n, double theta, bool
 // ------------------------------------------------------------------ Lyapunov solve (eigen-free NT scaling)
 // out = scale (T + T') by 32 x 32 tiles (both reads coalesced); with `dotp`: part[block] = sum dotp .* out over the block's
 // tiles.  out is exactly symmetric: (i,j) and (j,i) add the same two numbers.
-__global__ __launch_bounds__(256) void symadd_kernel(const double* __restrict__ T, int n, double scale, double* __restrict__ out,
+__global__ __launch_bounds__(256) void symadd_kernel(SlabSrc T, int n, double scale, double* __restrict__ out,
                                                      const double* __restrict__ dotp, double* __restrict__ part) {
   __shared__ double ta[32][33], tb[32][33];
   __shared__ double sh[4];
@@ -781,9 +781,9 @@ __global__ __launch_bounds__(256) void symadd_kernel(const double* __restrict__ 
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
       const int i = bi + tx, j = bj + r;       // tile (bi, bj): element (i, j)
-      ta[r][tx] = (i < n && j < n) ? T[(long)i + (long)j * n] : 0.0;
+      ta[r][tx] = (i < n && j < n) ? slab_sum(T, (long)i + (long)j * n) : 0.0;
       const int i2 = bj + tx, j2 = bi + r;     // tile (bj, bi): element (i2, j2)
-      tb[r][tx] = (i2 < n && j2 < n) ? T[(long)i2 + (long)j2 * n] : 0.0;
+      tb[r][tx] = (i2 < n && j2 < n) ? slab_sum(T, (long)i2 + (long)j2 * n) : 0.0;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -816,10 +816,21 @@ __device__ __forceinline__ double block_sum_parts(const double* __restrict__ par
 }
 
 // out = (M + M') / 2: the tiled kernel above from msz 512 on (the element-wise one reads M' with stride n)
+// C = alpha A Bm' for a consumer that can add split-K slabs while it reads: below msz 1500 on one rank the product may come
+// back as slabs (src->n > 1, C untouched); otherwise it is in C
+static int prod_slabs(lrn_ctx* c, hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha, int tri,
+                      SlabSrc* src) {
+  if (n >= 1500 || products_sharded(c, st, n)) {
+    src->p = C; src->stride = 0; src->n = 1;
+    return pgemm_nt(c, st, n, A, Bm, C, tri, alpha);
+  }
+  return gemm_nt_slabs(st, n, A, Bm, C, alpha, src);
+}
+
 static void sym_half(hipStream_t st, const double* M, double* out, int n) {
   if (n >= 512) {
     const long nt = (n + 31) / 32;
-    hipLaunchKernelGGL(symadd_kernel, dim3((unsigned)std::min<long>(1024, nt * nt)), dim3(256), 0, st, M, n, 0.5, out,
+    hipLaunchKernelGGL(symadd_kernel, dim3((unsigned)std::min<long>(1024, nt * nt)), dim3(256), 0, st, SlabSrc{M, 0, 1}, n, 0.5, out,
                        (const double*)nullptr, (double*)nullptr);
   } else {
     hipLaunchKernelGGL(sym_kernel, dim3(nbk((long)n * n)), dim3(256), 0, st, M, out, n);
@@ -967,8 +978,9 @@ static int lyap_solve(lrn_ctx* c, LmiBlock& b, double* Cm, double* R, double* wo
   while (k < maxit) {
     const int k1 = std::min(maxit, k + batch);
     for (; k < k1; ++k) {
-      LRN_TRY(pgemm_nt(c, st, n, Cop, p, work));
-      hipLaunchKernelGGL(symadd_kernel, dim3(np1), dim3(256), 0, st, work, n, 1.0, Ap, p, part1);
+      SlabSrc prod;                                  // (mid sizes: the slabs of the product are added by symadd_kernel)
+      LRN_TRY(prod_slabs(c, st, n, Cop, p, work, 1.0, 0, &prod));
+      hipLaunchKernelGGL(symadd_kernel, dim3(np1), dim3(256), 0, st, prod, n, 1.0, Ap, p, part1);
       hipLaunchKernelGGL(lyap_xr_kernel, dim3(np), dim3(256), 0, st, part1, np1, hist, k, p, Ap, R, r, nn, part2);
       hipLaunchKernelGGL(lyap_p_kernel, dim3(np), dim3(256), 0, st, part2, np, hist, k, r, p, nn);
     }
@@ -1204,16 +1216,18 @@ extern "C" int lrn_ip_find_step(lrn_ctx* c, int predict, double sigma_mu, double
       if (m >= 1500) {
         LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.LXt.as<double>(), b.Bs.as<double>(), 1.0, GEMM_KFROM_N));
       } else {
-        LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.LXt.as<double>(), t1, GEMM_KFROM_N));
-        hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, b.Bs.as<double>(), (const double*)nullptr,
+        SlabSrc prod;
+        LRN_TRY(prod_slabs(c, c->stream, m, t0, b.LXt.as<double>(), t1, 1.0, GEMM_KFROM_N, &prod));
+        hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, prod, m, 0.5, b.Bs.as<double>(), (const double*)nullptr,
                            (double*)nullptr);
       }
       LRN_TRY(pgemm_nt(c, c->stream, m, b.Zh.as<double>(), b.Bs.as<double>(), t0));
       if (m >= 1500) {
         LRN_TRY(pgemm_nt_sym(c, c->stream, m, t0, b.Zh.as<double>(), t3, 1.0 / b.ns_c));
       } else {
-        LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.Zh.as<double>(), t1, 0, 1.0 / b.ns_c));
-        hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, t1, m, 0.5, t3, (const double*)nullptr, (double*)nullptr);
+        SlabSrc prod;
+        LRN_TRY(prod_slabs(c, c->stream, m, t0, b.Zh.as<double>(), t1, 1.0 / b.ns_c, 0, &prod));
+        hipLaunchKernelGGL(symadd_kernel, dim3(gs), dim3(256), 0, c->stream, prod, m, 0.5, t3, (const double*)nullptr, (double*)nullptr);
       }
       hipLaunchKernelGGL(tx_kernel, dim3(g), dim3(256), 0, c->stream, t3, sigma_mu / b.ns_c, b.Ki.as<double>(),
                          predict ? (const double*)nullptr : b.RNT.as<double>(), b.TX.as<double>(), m);
@@ -1283,9 +1297,10 @@ extern "C" int lrn_ip_update(lrn_ctx* c, int predict, const double* alpha, const
         // Qm = L_X R L_X'
         tic(c);
         LRN_TRY(pgemm_nt(c, c->stream, m, b.TX.as<double>(), b.Bs.as<double>(), t0));              // N
-        LRN_TRY(pgemm_nt(c, c->stream, m, t0, b.Zh.as<double>(), t1));                             // N Zh
+        SlabSrc prod;
+        LRN_TRY(prod_slabs(c, c->stream, m, t0, b.Zh.as<double>(), t1, 1.0, 0, &prod));            // N Zh
         hipLaunchKernelGGL(symadd_kernel, dim3((unsigned)std::min<long>(1024, ((long)(m + 31) / 32) * ((m + 31) / 32))), dim3(256), 0,
-                           c->stream, t1, m, -1.0 / b.ns_c, t2, (const double*)nullptr, (double*)nullptr);
+                           c->stream, prod, m, -1.0 / b.ns_c, t2, (const double*)nullptr, (double*)nullptr);
         bool ok = false;
         int steps = 0;
         LRN_TRY(lyap_solve(c, b, t2, b.RNT.as<double>(), t0, &ok, &steps));

@@ -144,6 +144,21 @@ struct GemmDesc {
 };
 
 int gemm(hipStream_t st, const GemmDesc& d);
+// The result of a product as a sum of split-K slabs: value(e) = p[e] + p[stride + e] + ... (n slabs, fixed order -- the
+// sum reduce_slabs would store).  gemm_slabs runs gemm() but leaves the slabs of a mid-size product unreduced for a
+// consumer that adds them while it reads (a transpose, a symmetrisation, ...): n == 1 means the product is in d.C as usual.
+// The slab memory belongs to the stream: it is valid until the next product on the same stream.
+struct SlabSrc {
+  const double* p = nullptr;
+  long stride = 0;
+  int n = 1;
+};
+__device__ __forceinline__ double slab_sum(const SlabSrc& s, long e) {
+  double v = 0.0;
+  for (int k = 0; k < s.n; ++k) v += s.p[(long)k * s.stride + e];
+  return v;
+}
+int gemm_slabs(hipStream_t st, const GemmDesc& d, SlabSrc* out);
 const char* gemm_last_error();   // reason of this thread's last gemm() failure, or null
 // out[i] = beta*out[i] + sum_s slabs[s*stride + i]   (i < n), fixed summation order
 int reduce_slabs(hipStream_t st, const double* slabs, long stride, int nslab, double* out,

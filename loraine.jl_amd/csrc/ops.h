@@ -21,6 +21,11 @@ int nt_factor(lrn_ctx* c, LmiBlock& b, int* info, double* minpiv);
 // C = alpha A Bm' (n x n, column-major): the arrangement the direct-to-LDS GEMM kernel takes
 int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C, int flags = 0, double alpha = 1.0,
             double* Ct = nullptr);     // Ct: the transposed result as well
+// the same, a mid-size product left as its split-K slabs for a consumer that adds them while it reads (lrn_common.h, SlabSrc;
+// src->n == 1: the product is in C)
+int gemm_nt_slabs(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha, SlabSrc* src);
+// C and its transposed twin Ct from one pass over the slabs of a product (or over C itself when the product was not split)
+void slabs_to_c_and_ct(hipStream_t st, const SlabSrc& src, int n, double* C, double* Ct);
 // the same for a product that is symmetric in exact arithmetic; C comes back exactly symmetric
 int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha = 1.0, int tri = 0);
 // The same products for the resident path of a sharded run (one process per GPU): when the communicator has more than one

@@ -337,6 +337,69 @@ int gemm_nt(hipStream_t st, int n, const double* A, const double* Bm, double* C,
   return gemm(st, g);
 }
 
+int gemm_nt_slabs(hipStream_t st, int n, const double* A, const double* Bm, double* C, double alpha, SlabSrc* src) {
+  GemmDesc g;
+  g.A = A; g.sAm = 1; g.sAk = n;
+  g.B = Bm; g.sBk = n; g.sBn = 1;
+  g.C = C; g.sCm = 1; g.sCn = n;
+  g.M = g.N = g.K = n;
+  g.alpha = alpha;
+  return gemm_slabs(st, g, src);
+}
+
+// C = sum of the slabs, Ct = its transpose: 32 x 32 tiles through LDS (round 4: the slab addition of a mid-size product and
+// the transpose pass that followed it were two launches and two trips through memory)
+__global__ __launch_bounds__(256) void slabs_transpose_kernel(SlabSrc src, int n, double* __restrict__ C, double* __restrict__ Ct) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bx + tx, j = by + r;
+    if (i < n && j < n) {
+      const long e = (long)i + (long)j * n;
+      const double v = slab_sum(src, e);
+      tile[r][tx] = v;
+      if (src.n > 1 || src.p != C) C[e] = v;
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = by + tx, j = bx + r;      // Ct[i][j] = C[j][i]
+    if (i < n && j < n) Ct[(long)i + (long)j * n] = tile[tx][r];
+  }
+}
+
+void slabs_to_c_and_ct(hipStream_t st, const SlabSrc& src, int n, double* C, double* Ct) {
+  hipLaunchKernelGGL(slabs_transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, st, src, n, C, Ct);
+}
+
+// C = (S + S') / 2 for S = the sum of the slabs (or C itself, in place): the tile pair (bi, bj), (bj, bi) by one workgroup
+__global__ __launch_bounds__(256) void slabs_sym_kernel(SlabSrc src, int n, double* __restrict__ C) {
+  __shared__ double ta[32][33], tb[32][33];
+  const int nt = (n + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // pair index -> (bi <= bj)
+  int bj = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long)(bj + 1) * (bj + 2) / 2 <= (long)blockIdx.x) ++bj;
+  while ((long)bj * (bj + 1) / 2 > (long)blockIdx.x) --bj;
+  const int bi = (int)(blockIdx.x - (long)bj * (bj + 1) / 2);
+  if (bj >= nt) return;
+  const int oi = bi * 32, oj = bj * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = oi + tx, j = oj + r;       // tile (bi, bj): element (i, j)
+    ta[r][tx] = (i < n && j < n) ? slab_sum(src, (long)i + (long)j * n) : 0.0;
+    const int i2 = oj + tx, j2 = oi + r;     // tile (bj, bi): element (i2, j2)
+    tb[r][tx] = (i2 < n && j2 < n) ? slab_sum(src, (long)i2 + (long)j2 * n) : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = oi + tx, j = oj + r;
+    if (i < n && j < n) C[(long)i + (long)j * n] = 0.5 * (ta[r][tx] + tb[tx][r]);
+    const int i2 = oj + tx, j2 = oi + r;
+    if (bi != bj && i2 < n && j2 < n) C[(long)i2 + (long)j2 * n] = 0.5 * (tb[r][tx] + ta[tx][r]);
+  }
+}
+
 // (M + M')/2 in place
 __global__ void sym_inplace_kernel(double* __restrict__ M, int n) {
   long total = (long)n * n;
@@ -369,8 +432,10 @@ int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double
     hipLaunchKernelGGL(mirror_diag_tiles_kernel, dim3((n + 127) / 128), dim3(256), 0, st, C, n);
     return LRN_OK;
   }
-  LRN_TRY(gemm_nt(st, n, A, Bm, C, 0, alpha));
-  hipLaunchKernelGGL(sym_inplace_kernel, dim3(nb2((long)n * n)), dim3(256), 0, st, C, n);
+  SlabSrc src;
+  LRN_TRY(gemm_nt_slabs(st, n, A, Bm, C, alpha, &src));
+  const long nt = (n + 31) / 32;
+  hipLaunchKernelGGL(slabs_sym_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, src, n, C);
   return LRN_OK;
 }
 
@@ -590,6 +655,12 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   const bool dual = c->opt.ns_dual == 1 || (c->opt.ns_dual < 0 && n >= 1500);
   auto prod = [&](hipStream_t sx, const double* A, const double* Bm, double* C, double* Ct) -> int {
     if (dual) return pgemm_nt(c, sx, n, A, Bm, C, 0, 1.0, Ct);
+    if (!products_sharded(c, sx, n)) {
+      SlabSrc src;                                    // (a mid-size product: its slabs are added by the transpose pass)
+      LRN_TRY(gemm_nt_slabs(sx, n, A, Bm, C, 1.0, &src));
+      slabs_to_c_and_ct(sx, src, n, C, Ct);
+      return LRN_OK;
+    }
     LRN_TRY(pgemm_nt(c, sx, n, A, Bm, C, 0, 1.0));
     hipLaunchKernelGGL(transpose_kernel, tg, tb, 0, sx, C, n, Ct);
     return LRN_OK;
