@@ -63,6 +63,28 @@ def test_gemm_direct_to_lds_path(dev, M, N, K):
         assert not C[tiles[:, None] < tiles[None, :]].any()
 
 
+@pytest.mark.parametrize("M,N,K", [(2001, 2049, 301), (2177, 2001, 1001)])
+def test_gemm_direct_to_lds_path_odd_leading_dimensions(dev, M, N, K):
+    """Round 4: rows that are only 8-byte aligned (odd leading dimensions, lda = M, ldb = N) go through the same 16-byte
+    LDS DMA -- measured correct on gfx950 (tools/probe_unaligned_dma.py): the last pair of an odd row reads one element of
+    the next row (a row of C that is never stored) or, in the last row, past the descriptor's range (zero)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K))
+    C = dev.dbg_gemm(A, B, False, True, alpha=1.25)
+    assert relerr(C, 1.25 * A @ B.T) < 1e-14 * max(8, np.sqrt(K))
+
+
+@pytest.mark.parametrize("n", [801, 800, 640, 1111])
+def test_gemm_mid_size_slabs_kernel(dev, n):
+    """Round 4: a plain NT product whose 64-tiles do not fill the chip (msz 400 .. 1400) runs as split-K slabs on
+    gemm_f64_mid_kernel (three LDS stages filled by 16-byte DMA from rows of any 8-byte alignment, XOR-swizzled images,
+    1-D item grid) + reduce_slabs: against NumPy, odd and even sides."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)); B = rng.standard_normal((n, n))
+    C = dev.dbg_gemm(A, B, False, True, alpha=-0.5)
+    assert relerr(C, -0.5 * A @ B.T) < 1e-14 * np.sqrt(n)
+
+
 def test_gemm_splitk_matches(dev):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((5000, 300)); B = rng.standard_normal((5000, 260))
@@ -146,7 +168,7 @@ def test_potrs_superblock_path(dev, n):
     assert relerr(A @ x, b) < 1e-10
 
 
-@pytest.mark.parametrize("n", [9216, 9500, 10040])
+@pytest.mark.parametrize("n", [9216, 9500, 10040, 9217])
 def test_potrf_two_level_blocking(dev, n):
     """n >= 9000: super-blocks of 1024 columns -- inside one the steps update only its own remaining columns, the rest of
     the trailing matrix gets the sixteen panels at once (K = 1024 GEMM on the lower tiles), the next super-block starts with
