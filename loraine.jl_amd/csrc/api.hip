@@ -464,6 +464,17 @@ int lrn_dbg_gemm(lrn_ctx* c, int transA, int transB, int M, int N, int K, double
   } else {
     g.C = dC.as<double>(); g.sCm = 1; g.sCn = ldc; g.beta = beta;
     rc = gemm(c->stream, g);
+    static const int reps = getenv("LRN_DBG_GEMM_REPS") ? atoi(getenv("LRN_DBG_GEMM_REPS")) : 0;   // (measurement: time the product)
+    if (reps > 0 && rc == LRN_OK && beta == 0.0) {
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, c->stream);
+      for (int i = 0; i < reps; ++i) (void)gemm(c->stream, g);
+      (void)hipEventRecord(e1, c->stream); (void)hipEventSynchronize(e1);
+      float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+      fprintf(stderr, "[dbg_gemm] M %d N %d K %d flags %d: %.2f us per product (%d back to back)\n", M, N, K, flags, ms * 1e3 / reps, reps);
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
   }
   if (rc != LRN_OK) return set_error(c, rc, "gemm launch failed");
   rc = copy_out(c, C, dC.p, c_el * 8);

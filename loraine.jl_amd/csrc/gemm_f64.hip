@@ -1114,21 +1114,30 @@ static double* split_slabs(hipStream_t st, size_t bytes) {
 static int auto_split_factor(const GemmDesc& d) {
   static const int forced = getenv("LRN_GEMM_SPLIT") ? atoi(getenv("LRN_GEMM_SPLIT")) : -1;    // 0 / 1: off; k: k slabs
   if (forced == 0 || forced == 1) return 1;
-  if (d.ksplit > 1 || d.batch != 1 || d.flags != 0 || d.C2 || d.K < 512 || d.M < 128 || d.N < 128) return 1;
+  if (d.ksplit > 1 || d.batch != 1 || d.flags != 0 || d.C2 || d.K < 256 || d.M < 128 || d.N < 128) return 1;
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   if (t128 >= 256) return 1;                                   // the 128-tile kernels fill the chip by themselves
   const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-  if (t64 > 400) return 1;
   // C dense and contiguous (reduce_slabs adds flat vectors)
   const long a = d.sCm < 0 ? -d.sCm : d.sCm, b = d.sCn < 0 ? -d.sCn : d.sCn;
   if (!((a == 1 && b == d.M) || (b == 1 && a == d.N))) return 1;
   if (forced > 1) return forced > 8 ? 8 : forced;
-  long ks = (640 + t64 / 2) / t64;                             // aim at ~2.5 workgroups per CU
-  if (ks < 2) ks = 2;
-  if (ks > 4) ks = 4;
-  while (ks > 2 && d.K / ks < 128) --ks;
-  while (ks > 2 && t64 * ks > 512) --ks;                       // (gemm_f64_mid_kernel: two workgroups per CU, all resident)
-  return (int)ks;
+  // Round 4: the factor that minimises a small cost model of gemm_f64_mid_kernel (us; calibrated at msz 640 .. 1400,
+  // tools/gemm_nt_times.py): a CU shares its MFMA pipe between the workgroups it holds (three fit), one K-tile of one
+  // workgroup costs 0.515 us of it (1.5 x that when the workgroup is alone on its CU), plus launch and epilogue, plus -- for
+  // slabs -- the pass that adds them ((ks + 1) M N doubles at 4 TB/s and a launch).
+  int best = 1;
+  double best_us = 1e300;
+  for (int ks = 1; ks <= 4; ++ks) {
+    if (ks > 1 && d.K / ks < 96) break;
+    const long wgs = t64 * ks;
+    const long per_cu = (wgs + 255) / 256;
+    const double ktiles = std::ceil((double)d.K / 16.0 / ks);
+    double us = (double)per_cu * ktiles * 0.515 * (per_cu == 1 ? 1.5 : 1.0) + 5.0;
+    if (ks > 1) us += 4.0 + (double)(ks + 1) * (double)d.M * (double)d.N * 8.0 / 4.0e6;
+    if (us < best_us) { best_us = us; best = ks; }
+  }
+  return best;
 }
 
 static int gemm_maybe_slabs(hipStream_t st, const GemmDesc& din, SlabSrc* out) {
@@ -1203,8 +1212,11 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
   if ((d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)) return gemm_fail(LRN_ERR_ARG, "gemm: (d.flags & GEMM_C_PACKED) && (!swapped || d.pk_m <= 0 || d.beta != 0.0)");
   // tile choice: 128x128 unless the problem is too small to fill the chip with it
   long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * d.ksplit;
+  static const int mid_mode = getenv("LRN_GEMM_MID") ? atoi(getenv("LRN_GEMM_MID")) : 1;      // (measurement knob; 0: off)
   bool small = (d.flags & GEMM_SMALL_TILE) ||
                (t128 < 256 && !(d.flags & (GEMM_OFFDIAG_X2 | GEMM_C_PACKED | GEMM_C_MIRROR)) && !kseg && !kfrom);
+  // (measurement, LRN_GEMM_MID=2: plain products of up to 1024 128-tiles on the 64-tile DMA kernel as well)
+  if (mid_mode == 2 && t128 < 1024 && d.flags == 0 && !d.C2 && d.batch == 1 && d.beta == 0.0) small = true;
   const bool big = kflat && (d.flags & GEMM_TILE160);       // 160 x 160 tile of the K-contiguous rank-k update
   const int BMv = small ? 64 : (big ? 160 : 128);
   p.tilesM = (d.M + BMv - 1) / BMv;
@@ -1370,11 +1382,10 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     }
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
-  static const int mid_off = getenv("LRN_GEMM_MID") ? (atoi(getenv("LRN_GEMM_MID")) == 0) : 0;      // (measurement knob)
-  if (small && !mid_off && !kseg && !epi && d.batch == 1 && d.ksplit > 1 && d.beta == 0.0 && d.sAm == 1 && d.sBn == 1 &&
+  if (small && mid_mode != 0 && !kseg && !epi && d.batch == 1 && d.beta == 0.0 && d.sAm == 1 && d.sBn == 1 && d.K >= 64 &&
       d.sCn == 1 && d.sAk >= d.M && d.sBk >= d.N && !(d.flags & ~GEMM_SMALL_TILE) &&
       (double)d.K * (double)std::max(d.sAk, d.sBk) * 8.0 < 2.0e9) {
-    // the split-K slabs of a mid-size product (gemm() below): four-stage LDS DMA pipeline
+    // a plain mid-size product, or its split-K slabs (gemm() below): three-stage LDS DMA pipeline
     static const char* trace_path = getenv("LRN_MID_TRACE");       // (measurement: clocks of the workgroups of launch #40)
     static int trace_launch = 0;
     unsigned long long* tb = nullptr;
