@@ -75,7 +75,10 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * GEMM3' in one launch, 0: two launches), "gemm3_tile" (0 auto / 128 / 160), "gemm3_strip" (1: nvar % 128 in (0, 32] -> the last
  * 128 + nvar % 128 rows of H as a launch of 128 x 160 tiles instead of a row of edge tiles), "gemm_no_skip" (1: no block masks
  * in the three GEMMs of the factor path -- A/B switch), "gemm_dyn_masks" (1: the masked K-steps of GEMM1'/2' branch per
- * block as in round 2 -- A/B switch), "gemm3_stagger" (experiment: K-walk stagger of the workgroups of
+ * block as in round 2 -- A/B switch), "gemm1_diag" (1, default: GEMM1' leaves out the blocks of its diagonal tiles that
+ * GEMM2' never reads and stores zeros there; 0: computes them -- A/B switch, bit-identical), "gemm_lab" (measurement only:
+ * GEMM1'/2' without epilogue / K loop / first load, one workgroup per CU, whole K range, one matrix for every batch
+ * element -- tools/gemm12_overhead.py), "gemm3_stagger" (experiment: K-walk stagger of the workgroups of
  * GEMM3' in chunks of 16, 0 = off), "pair_lanes" (lanes per entry of the sparse pair kernel: 0 auto / 4 / 8 / 16 / 64),
  * "jacobi_cross" (1: cross-pair rotations only after round 0), "jacobi_early" (relative level below which a sweep's
  * rotations make it the last one; 0 = always run the confirming sweep), "eigmin_pair" (1: the two
