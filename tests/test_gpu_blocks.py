@@ -85,6 +85,17 @@ def test_gemm_mid_size_slabs_kernel(dev, n):
     assert relerr(C, -0.5 * A @ B.T) < 1e-14 * np.sqrt(n)
 
 
+@pytest.mark.parametrize("M,N,K", [(10, 500, 100), (257, 513, 1000), (64, 64, 64), (65, 63, 70), (1, 300, 64), (300, 1, 257),
+                                   (129, 1100, 333)])
+def test_gemm_mid_kernel_ragged_shapes(dev, M, N, K):
+    """gemm_f64_mid_kernel also serves unsplit plain NT products (beta = 0, K >= 64) of any shape that takes the 64 tile:
+    rows / columns beyond M / N and k-rows beyond K come back as zeros from the buffer descriptor's range check."""
+    rng = np.random.default_rng(M * 5 + N * 3 + K)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K))
+    C = dev.dbg_gemm(A, B, False, True, alpha=2.0)
+    assert relerr(C, 2.0 * A @ B.T) < 1e-14 * max(8, np.sqrt(K))
+
+
 def test_gemm_splitk_matches(dev):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((5000, 300)); B = rng.standard_normal((5000, 260))
