@@ -373,9 +373,13 @@ void slabs_to_c_and_ct(hipStream_t st, const SlabSrc& src, int n, double* C, dou
   hipLaunchKernelGGL(slabs_transpose_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, st, src, n, C, Ct);
 }
 
-// C = (S + S') / 2 for S = the sum of the slabs (or C itself, in place): the tile pair (bi, bj), (bj, bi) by one workgroup
-__global__ __launch_bounds__(256) void slabs_sym_kernel(SlabSrc src, int n, double* __restrict__ C) {
+// C = (S + S') / 2 for S = the sum of the slabs (or C itself, in place): the tile pair (bi, bj), (bj, bi) by one workgroup.
+// T != null: the Newton-Schulz pass on P = C in the same sweep -- T = a (3 I - a^2 P) / 2 and this workgroup's share of
+// ||I - P||_F^2 in part[blockIdx.x] (ns_t_kernel's work; C may then be null: nobody reads P itself)
+__global__ __launch_bounds__(256) void slabs_sym_kernel(SlabSrc src, int n, double* __restrict__ C, double a, double* __restrict__ T,
+                                                        double* __restrict__ part) {
   __shared__ double ta[32][33], tb[32][33];
+  __shared__ double sh[4];
   const int nt = (n + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   // pair index -> (bi <= bj)
@@ -392,12 +396,47 @@ __global__ __launch_bounds__(256) void slabs_sym_kernel(SlabSrc src, int n, doub
     tb[r][tx] = (i2 < n && j2 < n) ? slab_sum(src, (long)i2 + (long)j2 * n) : 0.0;
   }
   __syncthreads();
+  const double a3 = 0.5 * a * a * a, a1 = 1.5 * a;
+  double acc = 0.0;
   for (int r = ty; r < 32; r += 8) {
     const int i = oi + tx, j = oj + r;
-    if (i < n && j < n) C[(long)i + (long)j * n] = 0.5 * (ta[r][tx] + tb[tx][r]);
+    if (i < n && j < n) {
+      const double v = 0.5 * (ta[r][tx] + tb[tx][r]);
+      if (C) C[(long)i + (long)j * n] = v;
+      if (T) {
+        const double rr = (i == j ? 1.0 : 0.0) - v;
+        acc += rr * rr;
+        T[(long)i + (long)j * n] = (i == j ? a1 : 0.0) - a3 * v;
+      }
+    }
     const int i2 = oj + tx, j2 = oi + r;
-    if (bi != bj && i2 < n && j2 < n) C[(long)i2 + (long)j2 * n] = 0.5 * (tb[r][tx] + ta[tx][r]);
+    if (bi != bj && i2 < n && j2 < n) {
+      const double v = 0.5 * (tb[r][tx] + ta[tx][r]);
+      if (C) C[(long)i2 + (long)j2 * n] = v;
+      if (T) {
+        acc += v * v;                                  // (off the diagonal: the residual entry is -v)
+        T[(long)i2 + (long)j2 * n] = -a3 * v;
+      }
+    }
   }
+  if (!T || !part) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// P = A Bm' symmetrised (not stored) -> T = a (3 I - a^2 P) / 2, partial sums of ||I - P||_F^2 in part[0 .. *npart): the
+// Newton-Schulz step's first product with its element-wise pass folded into the slab addition (msz < 1500, one rank)
+int gemm_nt_sym_ns(hipStream_t st, int n, const double* A, const double* Bm, double* scratchC, double a, double* T, double* part,
+                   int* npart) {
+  SlabSrc src;
+  LRN_TRY(gemm_nt_slabs(st, n, A, Bm, scratchC, 1.0, &src));
+  const long nt = (n + 31) / 32;
+  *npart = (int)(nt * (nt + 1) / 2);
+  hipLaunchKernelGGL(slabs_sym_kernel, dim3((unsigned)*npart), dim3(256), 0, st, src, n, (double*)nullptr, a, T, part);
+  return LRN_OK;
 }
 
 // (M + M')/2 in place
@@ -435,7 +474,8 @@ int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double
   SlabSrc src;
   LRN_TRY(gemm_nt_slabs(st, n, A, Bm, C, alpha, &src));
   const long nt = (n + 31) / 32;
-  hipLaunchKernelGGL(slabs_sym_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, src, n, C);
+  hipLaunchKernelGGL(slabs_sym_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, src, n, C, 0.0, (double*)nullptr,
+                     (double*)nullptr);
   return LRN_OK;
 }
 
@@ -570,10 +610,11 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   b.chol_valid = false;            // (consumed: whoever changes X, S afterwards need not remember to reset it)
   for (DBuf* d : {&b.LXt, &b.Yh, &b.Zh, &b.Ki, &b.Bs, &b.TX, &b.Qm}) LRN_TRY(ensure(c, *d, mm));
   const int npart = (int)std::min<size_t>(1024, (nn + 255) / 256);
+  const int npart_alloc = std::max(npart, (int)((((long)n + 31) / 32) * (((long)n + 31) / 32 + 1) / 2));      // (gemm_nt_sym_ns: one per tile pair)
   const int maxit = std::max(4, std::min(c->opt.ns_maxit, 120));
   // scratch: P, T, Y' Z' of the resident set, a second set Ya Ya' Za Za', L_S^-1, L_S^-T (10 n^2), trsm work,
   // column norms, partial sums, residuals
-  size_t need = (10 * nn + (size_t)CHOL_NB * n + 2 * (size_t)n + npart + maxit + 64) * 8;
+  size_t need = (10 * nn + (size_t)CHOL_NB * n + 2 * (size_t)n + npart_alloc + maxit + 64) * 8;
   LRN_TRY(ensure(c, c->scratch, need));
   double* LXt = b.LXt.as<double>();
   double* Pm = c->scratch.as<double>();
@@ -590,7 +631,7 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
   double* colsum = tw2 + (size_t)CHOL_NB * n;
   double* colsq = colsum + n;
   double* part = colsq + n;
-  double* res = part + npart;        // res[0..maxit), then sc[0..1]
+  double* res = part + npart_alloc;  // res[0..maxit), then sc[0..1]
   double* sc = res + maxit;
   double *LX = b.LXf.as<double>(), *LS = b.LSf.as<double>();
   // (sharded products carry collectives: everything on the context's stream then, the order of the calls is the order of
@@ -682,9 +723,15 @@ int prepare_w_ns(lrn_ctx* c, LmiBlock& b, int* info, bool* converged) {
     // symmetric and Y T, T Z taken literally the iteration stays stable (residual floor 1e-12 instead of 1e-13, NumPy and
     // device) -- and T is its own transposed twin
     const double* Pk = Yc;                                // Z = I: P = Y (exactly symmetric)
-    if (!z_is_eye) { LRN_TRY(pgemm_nt_sym(c, st, n, Zc, Ytc, Pm, 1.0)); Pk = Pm; }
-    hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Pk, n, a, Tm, part);
-    hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, part, npart, res + k);
+    int np_k = npart;
+    if (!z_is_eye && n < 1500 && !products_sharded(c, st, n)) {
+      // (mid sizes: symmetrisation, T and the residual in the pass that adds the product's slabs)
+      LRN_TRY(gemm_nt_sym_ns(st, n, Zc, Ytc, Pm, a, Tm, part, &np_k));
+    } else {
+      if (!z_is_eye) { LRN_TRY(pgemm_nt_sym(c, st, n, Zc, Ytc, Pm, 1.0)); Pk = Pm; }
+      hipLaunchKernelGGL(ns_t_kernel, dim3(npart), dim3(256), 0, st, Pk, n, a, Tm, part);
+    }
+    hipLaunchKernelGGL(sum_sqrt_kernel, dim3(1), dim3(256), 0, st, part, np_k, res + k);
     double* const Tt = Tm;
     if (!z_is_eye && s3 != st) {
       LRN_HIP(c, hipEventRecord(c->evC, st));                                          // T, T' are final
