@@ -79,6 +79,83 @@ __global__ __launch_bounds__(256, WPE) void k3(P p) {
         if (m < p.M && n < p.N) cbase[(long)(32 * i + 4 * r) * p.ldc + 32 * j] = acc[i][j][r];
       }
 }
+// k4: 256 x 128 tile, 512 threads (8 waves, 4 x 2, 64 x 64 each), K-steps of 16, 106 KB of LDS: ONE workgroup per CU, the same two
+// waves per SIMD -- 0.75 of the panel bytes per flop, but all eight waves meet at one barrier per K-step
+__global__ __launch_bounds__(512, 2) void k4(P p) {
+  constexpr int BKL = 16, LRA = 272, LRB = 144, LA = BKL * LRA, LB = BKL * LRB;
+  extern __shared__ double lds[];               // 2 * (LA + LB) doubles
+  const int2 tt = p.tiles[blockIdx.x];
+  const int tm = tt.x, tn = tt.y, bz = blockIdx.z;      // rows [256 tm, +256), columns [128 tn, +128)
+  const double* Ag = p.A + (long)bz * p.bA;
+  const double* Bg = p.B + (long)bz * p.bB;
+  double* Cg = p.C + (long)bz * p.bC;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w & 3, wn = w >> 2;
+  const int m0 = tm * 256, n0 = tn * 128;
+  const unsigned bytesA = (unsigned)(((long)(p.K - 1) * p.lda + p.M) * 8);
+  const unsigned bytesB = (unsigned)(((long)(p.K - 1) * p.ldb + p.N) * 8);
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, bytesA, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bg, 0, bytesB, 0x00020000);
+  unsigned offA[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { const int ma = m0 + 128 * h + 2 * lane; offA[h] = ma < p.M ? (unsigned)ma * 8u : 0x80000000u; }
+  const int nb = n0 + 2 * lane;
+  const unsigned offB = nb < p.N ? (unsigned)nb * 8u : 0x80000000u;
+  const int nk = (p.K + BKL - 1) / BKL;
+  const int kt0 = p.kfrom ? n0 / BKL : 0;
+  v4f64 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  auto issue = [&](int kt, int buf) {
+    double* sa = lds + buf * (LA + LB);
+    double* sb = sa + LA;
+#pragma unroll
+    for (int j = 0; j < BKL / 8; ++j) {
+      const int kr = w + 8 * j;                        // eight waves: two k-rows each
+      const unsigned krow = (unsigned)(kt * BKL + kr);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(sa + kr * LRA + 128 * h), 16, (int)(offA[h] + krow * (unsigned)p.lda * 8u), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(sb + kr * LRB), 16, (int)(offB + krow * (unsigned)p.ldb * 8u), 0, 0, 0);
+    }
+  };
+  const int fr = lane & 15, fk = lane >> 4;
+  issue(kt0, kt0 & 1);
+  __syncthreads();
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+    const double* sa = lds + cur * (LA + LB);
+    const double* sb = sa + LA;
+#pragma unroll
+    for (int kk = 0; kk < BKL / 4; ++kk) {
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = sa[(kk * 4 + fk) * LRA + wm * 64 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = sb[(kk * 4 + fk) * LRB + wn * 64 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double* cbase = Cg + (long)(m0 + wm * 64 + (lane >> 4)) * p.ldc + (n0 + wn * 64 + fr);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r, n = n0 + wn * 64 + j * 16 + fr;
+        if (m < p.M && n < p.N) cbase[(long)(16 * i + 4 * r) * p.ldc + 16 * j] = acc[i][j][r];
+      }
+}
+
 __global__ void fill(double* x, long n, unsigned long seed) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     unsigned long z = (i + seed) * 0x9E3779B97F4A7C15ull; z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29;
@@ -115,6 +192,29 @@ int main(int argc, char** argv) {
       double ksteps = 0; for (auto& t : tl) ksteps += (kfrom ? n - 128 * t.y : n) / 16.0;
       printf("n %d batch %d kfrom %d %s: %.2f ms = %.3f ns per 128x128x16 tile-step, hip error %d\n", n, nb, kfrom,
              variant ? "BK 8, three workgroups per CU" : "BK 16, two workgroups per CU ", best, best * 1e6 / (ksteps * nb), (int)hipGetLastError());
+    }
+  }
+  {   // k4: 256 x 128 tiles (tm2, tn), any part on or below the diagonal: tn <= 2 tm2 + 1
+    std::vector<int2> t2;
+    const int nt2 = (n + 255) / 256;
+    for (int sn = 0; sn < nt; sn += 8) for (int sm = 0; sm < nt2; sm += 4)
+      for (int tn = sn; tn < sn + 8 && tn < nt; ++tn) for (int tm = sm; tm < sm + 4 && tm < nt2; ++tm) if (tn <= 2 * tm + 1) t2.push_back(make_int2(tm, tn));
+    int2* d2; hipMalloc(&d2, t2.size() * sizeof(int2)); hipMemcpy(d2, t2.data(), t2.size() * sizeof(int2), hipMemcpyHostToDevice);
+    const size_t ldsb = 2 * (16 * 272 + 16 * 144) * 8;
+    hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int kfrom = 1; kfrom >= 0; --kfrom) {
+      P p{A, L, C8, n, n, n, n, n, n, mm, 0, mm, kfrom, d2};
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k4, dim3((unsigned)t2.size(), 1, nb), dim3(512), ldsb, 0, p);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms;
+      }
+      double ksteps = 0; for (auto& t : t2) ksteps += 2.0 * (kfrom ? n - 128 * t.y : n) / 16.0;
+      printf("n %d batch %d kfrom %d 256 x 128 tile, one workgroup of eight waves per CU: %.2f ms = %.3f ns per executed 128x128x16 tile-step (%zu tiles), hip error %d\n",
+             n, nb, kfrom, best, best * 1e6 / (ksteps * nb), t2.size(), (int)hipGetLastError());
     }
   }
   // the two variants sum in the same order: compare
