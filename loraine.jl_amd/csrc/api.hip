@@ -98,7 +98,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "gemm_no_skip")) c->opt.gemm_no_skip = (int)value;
   else if (!strcmp(key, "gemm_dyn_masks")) c->opt.gemm_dyn_masks = (int)value;
   else if (!strcmp(key, "gemm1_diag")) c->opt.gemm1_diag = (int)value;
-  else if (!strcmp(key, "gemm_lab")) c->opt.gemm_lab = (int)value & 63;
+  else if (!strcmp(key, "gemm_lab")) c->opt.gemm_lab = (int)value & 127;
   else if (!strcmp(key, "gemm3_sched")) c->opt.gemm3_sched = (int)value;
   else if (!strcmp(key, "gemm3_tile")) c->opt.gemm3_tile = (int)value;
   else if (!strcmp(key, "gemm3_strip")) c->opt.gemm3_strip = (int)value;

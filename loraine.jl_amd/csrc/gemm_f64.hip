@@ -836,7 +836,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kseg_lds_kernel(GemmParams p)
   // a diagonal tile of a symmetric rank-k update (same operand, same rows): ONE panel serves as both images -- half
   // the loads of the tiles that, computing 10 of their 16 blocks, would otherwise be bound by the panel traffic
   const bool same_panel = (TBM == TBN) && (Ag == Bg) && (m0 == n0) && (d.sAm == d.sBn) && (d.M == d.N);
+  const long lab_kb = (d.flags & GEMM_LAB_SAME_CHUNK) ? chunk_base() : -1;       // (measurement only)
   auto issue = [&](long kb, int buf) {
+    if (lab_kb >= 0) kb = lab_kb;
     double* sa = lds + buf * (LA + LB);
     double* sb = sa + LA;
 #pragma unroll
@@ -1477,9 +1479,11 @@ int mfma_f64_peak(hipStream_t st, double* tflops) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const int iters = 4000;
+  // (round 4: 4000 iterations -- 0.9 ms -- measured the clock's ramp, not the pipe: 71-72 TFLOP/s where a run of 40 ms
+  // sustains 77.3-77.8 at 2.38-2.39 GHz, 64.0 shader cycles per MFMA of a SIMD; tools/lab/mfma_clock.hip)
+  const int iters = 100000;
   const int blocks = 256 * 2;       // 2 workgroups of 4 waves per CU -> 2 waves per SIMD
-  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dummy, 100);
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dummy, 20000);
   hipEventRecord(e0, st);
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, dummy, iters);
   hipEventRecord(e1, st);

@@ -67,6 +67,8 @@ enum : int {
   GEMM_DIAG_LOWER_Z = 262144, // direct-to-LDS kernel (GEMM1'): in diagonal tiles the 16x16 blocks above the block diagonal
                            // (m / 16 < n / 16) are not computed and STORED AS ZEROS (the caller multiplies them by zeros:
                            // stale NaNs must not be left there); a hint -- any other kernel computes them
+  GEMM_LAB_SAME_CHUNK = 1 << 25, // measurement only: the K-contiguous kernel (GEMM3') requests the FIRST chunk of its split at every K-step
+                                // (all panel loads hit in L2 after the first: what the kernel does when memory latency is out of the way)
   GEMM_LAB_NO_STORE = 1 << 20,  // measurement only (option "gemm_lab", tools/gemm12_overhead.py): direct-to-LDS kernel without
                                 // its epilogue
   GEMM_LAB_NO_KLOOP = 1 << 21,  // ... without its K loop (the first K-step is still loaded and waited for)

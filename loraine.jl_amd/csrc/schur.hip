@@ -649,7 +649,7 @@ static int assemble_dense_chol(lrn_ctx* c, LmiBlock& b, long P_cap) {
       g3.C = c->slabs.as<double>(); g3.sCm = 1; g3.sCn = M;
       g3.M = M; g3.N = N;
       g3.flags = GEMM_TRI_LOWER | GEMM_KFLAT | GEMM_DIAG_LOWER | (c->opt.gemm_no_skip ? GEMM_NO_SKIP : 0) |
-                 (t160 ? GEMM_TILE160 : 0);
+                 (t160 ? GEMM_TILE160 : 0) | ((c->opt.gemm_lab & 64) ? GEMM_LAB_SAME_CHUNK : 0);
       g3.kflat_total = Kp; g3.kflat_diag = Kd; g3.kflat_nsd = 1;
       g3.kflat_kb = kb.data(); g3.kflat_ke = ke.data();
       g3.kstagger = c->opt.gemm3_stagger;
