@@ -57,7 +57,31 @@ __global__ __launch_bounds__(256, 2) void g3(P p) {
     if (kt + 1 < nk) issue((long)(kt + 1) * BK, cur ^ 1);
     const double* sa = lds + cur * (2 * LA);
     const double* sb = sa + LA;
-    if constexpr (V == 0) {
+    if constexpr (V == 4 || V == 5) {
+      // the production reads (8 bytes, 2-way conflicts), but requested ahead of the MFMAs: V = 4 all four quarters first,
+      // V = 5 two quarters ahead (fragments of quarter kk + 2 requested before the MFMAs of quarter kk)
+      double fa[4][4], fb[4][4];
+      auto rd = [&](int kk) __attribute__((always_inline)) {
+        const int k = kk * 4 + fk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int row = (2 * i + wm) * 16 + fr; fa[kk][i] = sa[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int row = (2 * j + wn) * 16 + fr; fb[kk][j] = sb[row * BK + 2 * ((k >> 1) ^ ((row >> 1) & 7)) + (k & 1)]; }
+      };
+      auto mm = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+      };
+      if constexpr (V == 4) {
+        rd(0); __builtin_amdgcn_sched_barrier(0); rd(1); __builtin_amdgcn_sched_barrier(0); rd(2); __builtin_amdgcn_sched_barrier(0); rd(3);
+        __builtin_amdgcn_sched_barrier(0); mm(0); mm(1); mm(2); mm(3);
+      } else {
+        rd(0); __builtin_amdgcn_sched_barrier(0); rd(1); __builtin_amdgcn_sched_barrier(0); mm(0); __builtin_amdgcn_sched_barrier(0);
+        rd(2); __builtin_amdgcn_sched_barrier(0); mm(1); __builtin_amdgcn_sched_barrier(0); rd(3); __builtin_amdgcn_sched_barrier(0); mm(2); mm(3);
+      }
+    } else if constexpr (V == 0) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         double fa[4], fb[4];
@@ -135,6 +159,15 @@ int main(int argc, char** argv) {
   hipMemcpy(h.data(), C, (long)M * M * 8, hipMemcpyDeviceToHost);
   double d = 0, s = 0; for (long i = 0; i < (long)M * M; ++i) { d += (h[i] - h0[i]) * (h[i] - h0[i]); s += h0[i] * h0[i]; }
   tv[1] = run<2>(p); tv[2] = run<3>(p);
+  {
+    p.C = C;
+    float t4 = run<4>(p);
+    hipMemcpy(h.data(), C, (long)M * M * 8, hipMemcpyDeviceToHost);
+    long bad = 0; for (long i = 0; i < (long)M * M; ++i) bad += h[i] != h0[i];
+    float t5 = run<5>(p);
+    printf("V4 production reads, all four quarters requested first: %.2f ms = %.3f ns per tile-step = %.1f TFLOP/s (%ld entries differ from V0)\n", t4, t4 * 1e6 / steps, 524288.0 / (t4 * 1e6 / steps) / 1e3, bad);
+    printf("V5 production reads, two quarters ahead: %.2f ms = %.3f ns per tile-step = %.1f TFLOP/s\n", t5, t5 * 1e6 / steps, 524288.0 / (t5 * 1e6 / steps) / 1e3);
+  }
   const char* nm[3] = {"V1 16-byte reads, compiler's schedule", "V2 both groups first", "V3 group 1 after 16 MFMAs"};
   for (int v = 0; v < 3; ++v) printf("%s: %.2f ms = %.3f ns per tile-step = %.1f TFLOP/s\n", nm[v], tv[v], tv[v] * 1e6 / steps, 524288.0 / (tv[v] * 1e6 / steps) / 1e3);
   printf("V1 against V0: %.2e relative (another grouping of the k of a step)\n", sqrt(d / s));
