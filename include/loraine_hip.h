@@ -267,7 +267,8 @@ int lrn_get_timing(lrn_ctx* ctx, const char* key, double* ms);
 /* launch / event counters of the same phases; "shard_bs" returns the column-block width of the Schur
  * sharding in effect (option "shard_bs": 0 = auto, two 128-aligned blocks per rank) */
 int64_t lrn_get_count(lrn_ctx* ctx, const char* key);
-/* FP64 MFMA issue-rate probe (TFLOP/s of a register-only v_mfma_f64_16x16x4_f64 loop) */
+/* FP64 MFMA issue-rate probe (TFLOP/s of a register-only v_mfma_f64_16x16x4_f64 loop; an 8 ms warm-up launch and 43 ms
+ * timed, so that the clock's ramp after an idle period is not what is measured: 77.3-77.8 on an MI355X) */
 int lrn_mfma_f64_peak(lrn_ctx* ctx, double* tflops);
 /* placement probe: launches a (nx, 1, nz) grid of 256-thread workgroups and writes, for workgroup
  * (x, z), the XCC (XCD) id the hardware ran it on (HW_REG_XCC_ID) to out[x + nx*z] (host or device int32);
