@@ -1219,6 +1219,20 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
                (t128 < 256 && !(d.flags & (GEMM_OFFDIAG_X2 | GEMM_C_PACKED | GEMM_C_MIRROR)) && !kseg && !kfrom);
   // (measurement, LRN_GEMM_MID=2: plain products of up to 1024 128-tiles on the 64-tile DMA kernel as well)
   if (mid_mode == 2 && t128 < 1024 && d.flags == 0 && !d.C2 && d.batch == 1 && d.beta == 0.0) small = true;
+  // Round 4: one plain product of 256 .. 1023 128-tiles (msz 2000 .. 4000) does not fill whole rounds of the 512 workgroup
+  // slots with 128-tiles -- msz 3000: 576 tiles, the 64 of the second round run alone on their CUs, 1226 us where the
+  // 64-tile DMA kernel (2209 tiles on 768 slots) takes 1011.  Both kernels priced by the round model that fits
+  // tools/gemm_nt_times.py (its decisions match the measurements at msz 2100 .. 3800); the 128-tile kernel keeps the tie.
+  if (mid_mode == 1 && !small && t128 >= 256 && t128 < 1024 && d.flags == 0 && !d.C2 && d.batch == 1 && d.ksplit == 1 &&
+      d.beta == 0.0 && d.sAm == 1 && d.sBn == 1 && d.sCn == 1 && d.M == d.N) {
+    const double ks = (double)((d.K + BK - 1) / BK);
+    const long full = t128 / 512, rem = t128 % 512;
+    const double big_us = ks * 1.85 * (2.0 * full + (rem == 0 ? 0.0 : (rem <= 256 ? 1.25 : 2.0)));
+    const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    const long mfull = t64 / 768, mrem = t64 % 768, per_cu = (mrem + 255) / 256;
+    const double mid_us = mfull * 3.0 * ks * 0.515 + (mrem ? per_cu * ks * 0.515 * (per_cu == 1 ? 1.5 : 1.0) : 0.0);
+    if (mid_us * 1.08 < big_us * 1.03) small = true;
+  }
   const bool big = kflat && (d.flags & GEMM_TILE160);       // 160 x 160 tile of the K-contiguous rank-k update
   const int BMv = small ? 64 : (big ? 160 : 128);
   p.tilesM = (d.M + BMv - 1) / BMv;

@@ -74,6 +74,16 @@ def test_gemm_direct_to_lds_path_odd_leading_dimensions(dev, M, N, K):
     assert relerr(C, 1.25 * A @ B.T) < 1e-14 * max(8, np.sqrt(K))
 
 
+@pytest.mark.parametrize("n", [2200, 3001])
+def test_gemm_plain_products_that_do_not_fill_whole_rounds_of_128_tiles(dev, n):
+    """Round 4: a plain NT product of 256 .. 1023 128-tiles whose last round of workgroups would run half empty (msz 2200:
+    324 tiles, 3001: 576) goes to the 64-tile DMA kernel when the round model prices it cheaper (gemm_f64.hip)."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)); B = rng.standard_normal((n, n))
+    C = dev.dbg_gemm(A, B, False, True, alpha=0.5)
+    assert relerr(C, 0.5 * A @ B.T) < 1e-14 * np.sqrt(n)
+
+
 @pytest.mark.parametrize("n", [801, 800, 640, 1111])
 def test_gemm_mid_size_slabs_kernel(dev, n):
     """Round 4: a plain NT product whose 64-tiles do not fill the chip (msz 400 .. 1400) runs as split-K slabs on
