@@ -1116,10 +1116,13 @@ static double* split_slabs(hipStream_t st, size_t bytes) {
 static int auto_split_factor(const GemmDesc& d) {
   static const int forced = getenv("LRN_GEMM_SPLIT") ? atoi(getenv("LRN_GEMM_SPLIT")) : -1;    // 0 / 1: off; k: k slabs
   if (forced == 0 || forced == 1) return 1;
-  if (d.ksplit > 1 || d.batch != 1 || d.flags != 0 || d.C2 || d.K < 256 || d.M < 128 || d.N < 128) return 1;
+  // (flags: none, or GEMM_TRI_LOWER alone -- a symmetric product of which only the lower 64-tiles are wanted, gemm_slabs)
+  const bool tril = d.flags == GEMM_TRI_LOWER && d.M == d.N;
+  if (d.ksplit > 1 || d.batch != 1 || (d.flags != 0 && !tril) || d.C2 || d.K < 256 || d.M < 128 || d.N < 128) return 1;
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   if (t128 >= 256) return 1;                                   // the 128-tile kernels fill the chip by themselves
-  const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+  const long tm64 = (d.M + 63) / 64;
+  const long t64 = tril ? tm64 * (tm64 + 1) / 2 : tm64 * ((d.N + 63) / 64);
   // C dense and contiguous (reduce_slabs adds flat vectors)
   const long a = d.sCm < 0 ? -d.sCm : d.sCm, b = d.sCn < 0 ? -d.sCn : d.sCn;
   if (!((a == 1 && b == d.M) || (b == 1 && a == d.N))) return 1;
@@ -1130,7 +1133,7 @@ static int auto_split_factor(const GemmDesc& d) {
   // slabs -- the pass that adds them ((ks + 1) M N doubles at 4 TB/s and a launch).
   int best = 1;
   double best_us = 1e300;
-  for (int ks = 1; ks <= 4; ++ks) {
+  for (int ks = 1; ks <= (tril ? 6 : 4); ++ks) {
     if (ks > 1 && d.K / ks < 96) break;
     const long wgs = t64 * ks;
     const long per_cu = (wgs + 255) / 256;
@@ -1145,6 +1148,10 @@ static int auto_split_factor(const GemmDesc& d) {
 static int gemm_maybe_slabs(hipStream_t st, const GemmDesc& din, SlabSrc* out) {
   tls_gemm_error = nullptr;            // (a stale reason must not be appended to a later, unrelated error)
   const int ks = auto_split_factor(din);
+  if (din.flags == GEMM_TRI_LOWER && out && (ks < 2 || din.beta != 0.0)) {
+    out->p = nullptr; out->stride = 0; out->n = 0;     // (lower tiles as slabs or not at all: the caller takes its other route)
+    return LRN_OK;
+  }
   if (ks > 1) {
     const size_t mn = (size_t)din.M * din.N;
     double* slabs = split_slabs(st, mn * ks * 8);
@@ -1399,13 +1406,15 @@ static int gemm_impl(hipStream_t st, const GemmDesc& din) {
     return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
   }
   if (small && mid_mode != 0 && !kseg && !epi && d.batch == 1 && d.beta == 0.0 && d.sAm == 1 && d.sBn == 1 && d.K >= 64 &&
-      d.sCn == 1 && d.sAk >= d.M && d.sBk >= d.N && !(d.flags & ~GEMM_SMALL_TILE) &&
+      d.sCn == 1 && d.sAk >= d.M && d.sBk >= d.N && !(d.flags & ~(GEMM_SMALL_TILE | GEMM_TRI_LOWER | GEMM_TRI_UPPER)) &&
+      (!tri || (d.M == d.N && d.ksplit > 1)) &&
       (double)d.K * (double)std::max(d.sAk, d.sBk) * 8.0 < 2.0e9) {
     // a plain mid-size product, or its split-K slabs (gemm() below): three-stage LDS DMA pipeline
     static const char* trace_path = getenv("LRN_MID_TRACE");       // (measurement: clocks of the workgroups of launch #40)
     static int trace_launch = 0;
     unsigned long long* tb = nullptr;
-    p.n1 = p.tilesM * p.tilesN * d.ksplit;                        // (flags == 0: every tile of the grid, real entries first in the list)
+    // (every tile of the grid, or its lower / upper triangle; the real entries come first in the list)
+    p.n1 = (tri ? p.tilesM * (p.tilesM + 1) / 2 : p.tilesM * p.tilesN) * d.ksplit;
     grid = dim3((unsigned)((p.n1 + 7) & ~7), 1, 1);
     const size_t tw = 8 * (size_t)grid.x * grid.z;
     if (trace_path && ++trace_launch == 40 && hipMalloc(&tb, tw * 8) == hipSuccess) {

@@ -427,14 +427,91 @@ __global__ __launch_bounds__(256) void slabs_sym_kernel(SlabSrc src, int n, doub
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// The same from slabs that hold only the LOWER 64-tiles of the product (rows i, columns j with i / 64 >= j / 64; gemm_slabs
+// with GEMM_TRI_LOWER: half the MFMA work).  The pair of 32-tiles (bi <= bj) is filled from the lower one, (bj, bi): C over
+// there = the sum, C over here = its transpose; inside a diagonal 32-tile the lower triangle is mirrored.  The result is
+// the product's lower triangle mirrored -- exactly symmetric, NOT the average of the two triangles that slabs_sym_kernel
+// forms (the form the products of msz >= 1500 have had since round 3: lower tiles + mirror).
+__global__ __launch_bounds__(256) void slabs_symlow_kernel(SlabSrc src, int n, double* __restrict__ C, double a, double* __restrict__ T,
+                                                           double* __restrict__ part) {
+  __shared__ double tl[32][33];
+  __shared__ double sh[4];
+  const int nt = (n + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  int bj = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((long)(bj + 1) * (bj + 2) / 2 <= (long)blockIdx.x) ++bj;
+  while ((long)bj * (bj + 1) / 2 > (long)blockIdx.x) --bj;
+  const int bi = (int)(blockIdx.x - (long)bj * (bj + 1) / 2);
+  if (bj >= nt) return;
+  const int oi = bi * 32, oj = bj * 32;          // lower tile: rows oj .., columns oi ..
+  for (int r = ty; r < 32; r += 8) {
+    const int i = oj + tx, j = oi + r;           // element (i, j) of the lower tile, i fastest
+    tl[r][tx] = (i < n && j < n) ? slab_sum(src, (long)i + (long)j * n) : 0.0;
+  }
+  __syncthreads();
+  const double a3 = 0.5 * a * a * a, a1 = 1.5 * a;
+  double acc = 0.0;
+  for (int r = ty; r < 32; r += 8) {
+    {   // the lower tile itself: element (oj + tx, oi + r)
+      const int i = oj + tx, j = oi + r;
+      if (i < n && j < n) {
+        const double v = (bi == bj && tx < r) ? tl[tx][r] : tl[r][tx];       // diagonal tile: (i, j) above the diagonal <- (j, i)
+        if (C) C[(long)i + (long)j * n] = v;
+        if (T) {
+          const double rr = (i == j ? 1.0 : 0.0) - v;
+          acc += rr * rr;
+          T[(long)i + (long)j * n] = (i == j ? a1 : 0.0) - a3 * v;
+        }
+      }
+    }
+    if (bi != bj) {   // its mirror image: element (oi + tx, oj + r) = lower (oj + r, oi + tx)
+      const int i = oi + tx, j = oj + r;
+      if (i < n && j < n) {
+        const double v = tl[tx][r];
+        if (C) C[(long)i + (long)j * n] = v;
+        if (T) {
+          acc += v * v;
+          T[(long)i + (long)j * n] = -a3 * v;
+        }
+      }
+    }
+  }
+  if (!T || !part) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// the lower 64-tiles of C = alpha A Bm' as split-K slabs (src->n == 0: not available for this size -- take the full product)
+static int gemm_nt_lower_slabs(hipStream_t st, int n, const double* A, const double* Bm, double alpha, SlabSrc* src) {
+  static const bool off = getenv("LRN_SYM_LOWER_OFF") != nullptr;      // (measurement knob)
+  src->p = nullptr; src->stride = 0; src->n = 0;
+  if (off) return LRN_OK;
+  GemmDesc g;
+  g.A = A; g.sAm = 1; g.sAk = n;
+  g.B = Bm; g.sBk = n; g.sBn = 1;
+  g.C = nullptr; g.sCm = 1; g.sCn = n;
+  g.M = g.N = g.K = n;
+  g.alpha = alpha;
+  g.flags = GEMM_TRI_LOWER;
+  return gemm_slabs(st, g, src);
+}
+
 // P = A Bm' symmetrised (not stored) -> T = a (3 I - a^2 P) / 2, partial sums of ||I - P||_F^2 in part[0 .. *npart): the
 // Newton-Schulz step's first product with its element-wise pass folded into the slab addition (msz < 1500, one rank)
 int gemm_nt_sym_ns(hipStream_t st, int n, const double* A, const double* Bm, double* scratchC, double a, double* T, double* part,
                    int* npart) {
   SlabSrc src;
-  LRN_TRY(gemm_nt_slabs(st, n, A, Bm, scratchC, 1.0, &src));
   const long nt = (n + 31) / 32;
   *npart = (int)(nt * (nt + 1) / 2);
+  LRN_TRY(gemm_nt_lower_slabs(st, n, A, Bm, 1.0, &src));
+  if (src.n > 0) {
+    hipLaunchKernelGGL(slabs_symlow_kernel, dim3((unsigned)*npart), dim3(256), 0, st, src, n, (double*)nullptr, a, T, part);
+    return LRN_OK;
+  }
+  LRN_TRY(gemm_nt_slabs(st, n, A, Bm, scratchC, 1.0, &src));
   hipLaunchKernelGGL(slabs_sym_kernel, dim3((unsigned)*npart), dim3(256), 0, st, src, n, (double*)nullptr, a, T, part);
   return LRN_OK;
 }
@@ -472,8 +549,14 @@ int gemm_nt_sym(hipStream_t st, int n, const double* A, const double* Bm, double
     return LRN_OK;
   }
   SlabSrc src;
-  LRN_TRY(gemm_nt_slabs(st, n, A, Bm, C, alpha, &src));
   const long nt = (n + 31) / 32;
+  LRN_TRY(gemm_nt_lower_slabs(st, n, A, Bm, alpha, &src));
+  if (src.n > 0) {      // (round 4: lower 64-tiles only + mirror, as the products of msz >= 1500)
+    hipLaunchKernelGGL(slabs_symlow_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, src, n, C, 0.0, (double*)nullptr,
+                       (double*)nullptr);
+    return LRN_OK;
+  }
+  LRN_TRY(gemm_nt_slabs(st, n, A, Bm, C, alpha, &src));
   hipLaunchKernelGGL(slabs_sym_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, src, n, C, 0.0, (double*)nullptr,
                      (double*)nullptr);
   return LRN_OK;
