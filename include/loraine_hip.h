@@ -228,6 +228,13 @@ int lrn_dbg_lanczos(lrn_ctx* ctx, int n, int k, const double* M, double* lam_top
  * ((K/c)^1/2, (K/c)^-1/2 for K = L_X' S L_X), "Qm" (G RNT G' of the predictor).  *flag (may be NULL) receives 1 when the
  * current scaling of the block is the eigen-free one, and c = lrn_get_timing("ns_c") its scale. */
 int lrn_dbg_get_block(lrn_ctx* ctx, int il, const char* name, double* out, int* flag);
+/* Host only (no context, no GPU): k-th smallest eigenvalue (k = 0 .. m-1) of the symmetric tridiagonal matrix with diagonal
+ * a[0..m) and off-diagonal b[0..m-1), as the Lanczos drivers of the step-length rule and of the H_alpha setup compute it after
+ * every batch of steps (csrc/tridiag.h; reference: eigmin(XXX), src/predictor_corrector.jl:272,285, and eigen(W),
+ * src/Solvers.jl:642,706).  upper (may be NULL): a value believed to be >= that eigenvalue (checked, never trusted);
+ * width: how far it is expected to lie below (<= 0: unknown).  evals (may be NULL): Sturm counts evaluated. */
+int lrn_dbg_tridiag_eig(int m, const double* a, const double* b, int k, const double* upper, double width, double* eig,
+                        int64_t* evals);
 
 /* ---- multi-GPU: one process per GPU, the exchange inside the library ---------------------------------------
  * The reference is one process (no MPI/NCCL); a sharded run keeps its predictor / corrector loop

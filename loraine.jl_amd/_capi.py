@@ -73,6 +73,7 @@ SIGNATURES = {
     "lrn_ip_update": (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lrn_ip_stats": (C.c_int, [c_ctx, C.c_void_p]),
     "lrn_dbg_get_block": (C.c_int, [c_ctx, C.c_int, C.c_char_p, C.c_void_p, PI]),
+    "lrn_dbg_tridiag_eig": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, PD, PI64]),
     "lrn_dbg_eigmin": (C.c_int, [c_ctx, C.c_int, C.c_void_p, PD, PI]),
     "lrn_dbg_lanczos": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, PD, PD, PI]),
     "lrn_get_timing": (C.c_int, [c_ctx, C.c_char_p, PD]),

@@ -1991,7 +1991,11 @@ extern "C" int lrn_pcg(lrn_ctx* c, const double* h, double tol, int maxit, doubl
   LRN_TRY(copy_in(c, c->v0.p, h, (size_t)n * 8));
   hipEvent_t a0, a1;
   if (c->profile) { (void)hipEventCreate(&a0); (void)hipEventCreate(&a1); (void)hipEventRecord(a0, c->stream); }
-  LRN_TRY(pcg_dev(c, c->v0.as<double>(), tol, maxit, c->v3.as<double>(), exit_code, iters));
+  const int rc = pcg_dev(c, c->v0.as<double>(), tol, maxit, c->v3.as<double>(), exit_code, iters);
+  if (rc != LRN_OK) {
+    if (c->profile) { (void)hipEventDestroy(a0); (void)hipEventDestroy(a1); }
+    return rc;
+  }
   if (c->profile) {
     (void)hipEventRecord(a1, c->stream); (void)hipEventSynchronize(a1);
     float ms = 0; (void)hipEventElapsedTime(&ms, a0, a1);

@@ -18,6 +18,7 @@
 
 #include "../../include/loraine_hip.h"
 #include "ops.h"
+#include "tridiag.h"
 
 namespace lrn {
 
@@ -322,7 +323,7 @@ static bool lz_big_lds_ok() {
 // workgroup, acquire fence; every workgroup executes the same number of barriers).  The kernel can NOT hang: a workgroup
 // that waits longer than `limit` ticks of the 100 MHz wall clock (its peers were not scheduled -- a GPU shared with another
 // process, an over-subscribed chip) raises flag[1], every workgroup leaves at its next barrier, and the host redoes the run
-// with one launch per step (lz_collect).  flag[0]: the counter, flag[1]: abort.
+// with one launch per step (lz_fetch).  flag[0]: the counter, flag[1]: abort.
 __device__ __forceinline__ bool lz_grid_barrier(unsigned* flag, unsigned target, long long limit, int* ok_s) {
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -375,59 +376,8 @@ int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int q
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }
 
-// smallest eigenvalue of the symmetric tridiagonal (a_0..a_{m-1}; b_0..b_{m-2}) by bisection
-static double tridiag_min(const std::vector<double>& a, const std::vector<double>& b, int m) {
-  double lo = a[0], hi = a[0];
-  for (int i = 0; i < m; ++i) {
-    double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < m - 1 ? std::fabs(b[i]) : 0.0);
-    lo = std::min(lo, a[i] - r);
-    hi = std::max(hi, a[i] + r);
-  }
-  auto count_below = [&](double x) {   // number of eigenvalues < x (Sturm sequence)
-    int cnt = 0;
-    double d = 1.0;
-    for (int i = 0; i < m; ++i) {
-      double bb = i > 0 ? b[i - 1] * b[i - 1] : 0.0;
-      d = a[i] - x - (i > 0 ? bb / d : 0.0);
-      if (d == 0.0) d = -1e-300;
-      if (d < 0.0) ++cnt;
-    }
-    return cnt;
-  };
-  for (int it = 0; it < 200; ++it) {
-    double mid = 0.5 * (lo + hi);
-    if (mid == lo || mid == hi) break;
-    if (count_below(mid) >= 1) hi = mid; else lo = mid;
-  }
-  return 0.5 * (lo + hi);
-}
-
-// k-th smallest eigenvalue (k = 0, 1, ...) of the symmetric tridiagonal matrix by bisection on the Sturm count
-static double tridiag_kth(const std::vector<double>& a, const std::vector<double>& b, int m, int k) {
-  double lo = a[0], hi = a[0];
-  for (int i = 0; i < m; ++i) {
-    double r = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i < m - 1 ? std::fabs(b[i]) : 0.0);
-    lo = std::min(lo, a[i] - r);
-    hi = std::max(hi, a[i] + r);
-  }
-  auto count_below = [&](double x) {
-    int cnt = 0;
-    double d = 1.0;
-    for (int i = 0; i < m; ++i) {
-      double bb = i > 0 ? b[i - 1] * b[i - 1] : 0.0;
-      d = a[i] - x - (i > 0 ? bb / d : 0.0);
-      if (d == 0.0) d = -1e-300;
-      if (d < 0.0) ++cnt;
-    }
-    return cnt;
-  };
-  for (int it = 0; it < 200; ++it) {
-    double mid = 0.5 * (lo + hi);
-    if (mid == lo || mid == hi) break;
-    if (count_below(mid) >= k + 1) hi = mid; else lo = mid;
-  }
-  return 0.5 * (lo + hi);
-}
+// (the eigenvalues of the tridiagonal matrices: tridiag.h -- bisection on a division-free Sturm count, bracket from the
+// previous batch's value)
 
 // |beta_m * s_m| for the Ritz pair (theta, s) of T_m: the residual norm ||M v - theta v|| of the
 // Ritz vector, a rigorous bound on the distance from theta to the spectrum.  s by two steps of
@@ -472,6 +422,10 @@ struct LzRun {
   int nchunk = 1, cper = 1, mmax = 0, m = 0, m1 = 0;
   std::vector<double> a, b, hab;
   double theta = 0.0, theta_prev = 0.0, scale = 0.0;
+  double last_move = 0.0;                   // |theta - theta_prev| of the last collect: how far the next one is expected to move
+  int mc = 0;                               // steps whose coefficients the host holds (lz_fetch); a batch [mc, m1) may be queued ahead
+  bool ahead = false;
+  double err_prev = 0.0, err_last = 0.0;    // residual / (1e-3 x its scale) at the last two looks (0: none): lz_queue_ahead
   bool have_prev = false, conv = false, done = false;
   bool fused = false;                       // lz_fused_kernel: Q3 = q (3 n), Y2 = w (2 n), PA2 = ypart (2 nwg)
   int nwg = 0;
@@ -536,8 +490,8 @@ static void lz_launch(LzRun& r) {
   }
 }
 
-// waits for the batch in flight and decides: r.done when converged, settled or out of steps
-static int lz_collect(lrn_ctx* c, LzRun& r) {
+// waits for the batch in flight and brings its coefficients: r.mc steps are on the host afterwards
+static int lz_fetch(lrn_ctx* c, LzRun& r) {
   const int m1 = r.m1;
   r.hab.resize(2 * (size_t)m1);
   LRN_HIP(c, hipMemcpyAsync(r.hab.data(), r.ab, (size_t)2 * m1 * 8, hipMemcpyDeviceToHost, r.st));
@@ -551,10 +505,38 @@ static int lz_collect(lrn_ctx* c, LzRun& r) {
     c->counts["lz_persist_abort"] += 1;
     r.persist = false;
     r.m = 0; r.have_prev = false; r.scale = 0.0;
+    r.err_prev = r.err_last = 0.0;
     lz_start(r);
     lz_launch(r);
-    return lz_collect(c, r);
+    return lz_fetch(c, r);
   }
+  r.mc = m1;
+  r.m = m1;
+  r.ahead = false;
+  return LRN_OK;
+}
+
+// A run that is alone on the GPU (its partner of eigmin_dev_pair has ended, or eigmin_dev) leaves the stream empty while
+// the host looks at T: a synchronisation, a bisection, an inverse iteration and the first launch of the next batch, ~50 us
+// per 117 us batch (maxG11: 7.3 us per step in runs of 16-30 steps, 12 in runs of 120).  Between lz_fetch and lz_decide:
+// when the last two looks say that the coming one cannot end the run -- the residual, extrapolated geometrically, stays
+// above 1e-2 of its scale, out of reach of every rule of lz_decide (the Kato-Temple rule needs 1e-3, the plain one 1e-11;
+// the sign-class rule is excluded by theta < 0) -- the next batch is queued before that look.  Timing only: the looks and
+// their verdicts are the same; a batch queued in vain is ignored (eigmin_dev_pair makes c->stream wait for it).
+static void lz_queue_ahead(lrn_ctx* c, LzRun& r) {
+  static const bool off = getenv("LRN_LZ_NOAHEAD") != nullptr;      // (measurement knob)
+  if (off || r.persist || r.ahead || r.mc >= r.mmax || !(r.err_prev > 0.0) || !(r.err_last > 0.0)) return;
+  if (!(r.theta_prev < 0.0)) return;
+  const double next = r.err_last * std::min(1.0, r.err_last / r.err_prev);
+  if (!(next > 10.0)) return;
+  lz_launch(r);                       // (r.m == r.mc: the batch [mc, m1))
+  r.ahead = true;
+  c->counts["lanczos_ahead"] += 1;
+}
+
+// the look at T of the fetched steps: r.done when converged, settled or out of steps
+static int lz_decide(lrn_ctx* c, LzRun& r) {
+  const int m1 = r.mc;
   r.a.resize(m1); r.b.resize(m1);
   int mm_ = m1;
   for (int j = 0; j < m1; ++j) {
@@ -562,19 +544,21 @@ static int lz_collect(lrn_ctx* c, LzRun& r) {
     r.scale = std::max(r.scale, std::fabs(r.a[j]) + std::fabs(r.b[j]));
     if (!(r.b[j] > 1e-14 * r.scale) && j + 1 < m1) { mm_ = j + 1; break; }      // invariant subspace
   }
-  r.theta = tridiag_min(r.a, r.b, mm_);
-  r.m = m1;
+  // T of the previous batch is a leading block of this one: its smallest eigenvalue bounds this one from above
+  r.theta = tri_eig_kth(r.a, r.b, mm_, 0, r.have_prev ? &r.theta_prev : nullptr, r.last_move);
   if (mm_ < m1) { r.conv = true; r.done = true; return LRN_OK; }
   // stop on the rigorous residual bound; for a clearly non-negative spectrum (theta > 0 is an
   // upper bound of lambda_min) the callers only need the sign class once theta has settled
   const double res = ritz_residual(r.a, r.b, mm_, r.theta);
+  r.err_prev = r.err_last;
+  r.err_last = res / (1e-3 * std::max(std::max(std::fabs(r.theta), 1e-4 * r.scale), 1e-300));
   if (res <= 1e-11 * std::max(std::fabs(r.theta), 1e-4 * r.scale)) { r.conv = true; r.done = true; return LRN_OK; }
   // Kato-Temple: theta - lambda_min <= res^2 / (lambda_2 - theta).  lambda_2 is bounded below through the second Ritz
   // pair (an eigenvalue lies within res2 of theta2; if that eigenvalue is lambda_min itself -- a ghost copy -- the gap
   // below is <= 0 and the rule does not fire).  The step-length rule consumes lambda_min to ~1e-10 relative.
   static const double kt_tol = getenv("LRN_EIGMIN_KT") ? atof(getenv("LRN_EIGMIN_KT")) : 1e-10;
   if (kt_tol > 0.0 && mm_ >= 8 && r.theta <= -1e-6 && res <= 1e-3 * std::max(std::fabs(r.theta), 1e-4 * r.scale)) {
-    const double th2 = tridiag_kth(r.a, r.b, mm_, 1);
+    const double th2 = tri_eig_kth(r.a, r.b, mm_, 1);
     const double res2 = ritz_residual(r.a, r.b, mm_, th2);
     const double gap = (th2 - res2) - r.theta;
     if (gap > 0.0 && res < 0.25 * gap && res * res / gap <= kt_tol * std::fabs(r.theta)) {
@@ -582,10 +566,11 @@ static int lz_collect(lrn_ctx* c, LzRun& r) {
       return LRN_OK;
     }
   }
-  if (r.have_prev && r.theta > 0.0 && std::fabs(r.theta - r.theta_prev) <= 1e-3 * r.theta && r.m >= 64) { r.done = true; return LRN_OK; }
+  if (r.have_prev && r.theta > 0.0 && std::fabs(r.theta - r.theta_prev) <= 1e-3 * r.theta && r.mc >= 64) { r.done = true; return LRN_OK; }
+  r.last_move = r.have_prev ? std::fabs(r.theta - r.theta_prev) : 0.0;
   r.theta_prev = r.theta;
   r.have_prev = true;
-  if (r.m >= r.mmax) r.done = true;
+  if (r.mc >= r.mmax) r.done = true;
   return LRN_OK;
 }
 
@@ -614,8 +599,8 @@ int lanczos_ends(lrn_ctx* c, const double* M, int n, int nsteps, double* lo, dou
     if (!(b[j] > 1e-14 * scale) && j + 1 < m) { mm_ = j + 1; break; }      // invariant subspace: the Ritz values are exact
   }
   if (!(scale == scale) || mm_ < 1) return set_error(c, LRN_ERR_STATE, "lanczos_ends: not a finite matrix");
-  *lo = tridiag_min(a, b, mm_);
-  const double top = -tridiag_min(an, b, mm_);       // largest eigenvalue of T = - smallest of -T (same off-diagonal)
+  *lo = tri_eig_kth(a, b, mm_, 0);
+  const double top = -tri_eig_kth(an, b, mm_, 0);    // largest eigenvalue of T = - smallest of -T (same off-diagonal)
   *hi = top;
   *res_hi = mm_ < m ? 0.0 : ritz_residual(an, b, mm_, -top);
   c->counts["lanczos_ends_steps"] += m;
@@ -635,8 +620,10 @@ int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, 
   LRN_TRY(lz_begin(c, r, M, n, c->stream, c->lzbuf));
   lz_start(r);
   while (!r.done) {
-    lz_launch(r);
-    LRN_TRY(lz_collect(c, r));
+    if (!r.ahead) lz_launch(r);
+    LRN_TRY(lz_fetch(c, r));
+    lz_queue_ahead(c, r);                    // (alone on the GPU: see there)
+    LRN_TRY(lz_decide(c, r));
   }
   *lam = r.theta;
   c->counts["lanczos_steps"] += r.m;
@@ -665,9 +652,15 @@ static int eigmin_dev_pair(lrn_ctx* c, const double* M1, const double* M2, int n
   while (!r[0].done || !r[1].done) {
     for (int k = 0; k < 2; ++k) {
       if (r[k].done) continue;
-      LRN_TRY(lz_collect(c, r[k]));          // (the other run's batch keeps the GPU busy meanwhile)
-      if (!r[k].done) lz_launch(r[k]);
+      LRN_TRY(lz_fetch(c, r[k]));
+      if (r[1 - k].done) lz_queue_ahead(c, r[k]);      // (otherwise the other run's batch keeps the GPU busy meanwhile)
+      LRN_TRY(lz_decide(c, r[k]));
+      if (!r[k].done && !r[k].ahead) lz_launch(r[k]);
     }
+  }
+  if (r[1].ahead) {                          // a batch queued in vain on stream2 still reads M2 and its workspace
+    LRN_HIP(c, hipEventRecord(c->ev1, c->stream2));
+    LRN_HIP(c, hipStreamWaitEvent(c->stream, c->ev1, 0));
   }
   for (int k = 0; k < 2; ++k) {
     lam[k] = r[k].theta; conv[k] = r[k].conv; scale[k] = r[k].scale;
