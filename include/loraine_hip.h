@@ -81,8 +81,9 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * element -- tools/gemm12_overhead.py), "gemm3_stagger" (experiment: K-walk stagger of the workgroups of
  * GEMM3' in chunks of 16, 0 = off), "pair_lanes" (lanes per entry of the sparse pair kernel: 0 auto / 4 / 8 / 16 / 64),
  * "jacobi_cross" (1: cross-pair rotations only after round 0), "jacobi_early" (relative level below which a sweep's
- * rotations make it the last one; 0 = always run the confirming sweep), "eigmin_pair" (1: the two
- * smallest-eigenvalue searches of a step-length computation as interleaved Lanczos runs on two streams),
+ * rotations make it the last one; 0 = always run the confirming sweep), "eigmin_pair" (the two
+ * smallest-eigenvalue searches of a step-length computation: 2, default = their Lanczos runs in lock-step, one launch per
+ * pair of steps; 1 = as two launch chains on two streams; 0 = one after the other -- same results),
  * "prepw_streams" (1: lrn_prepare_w runs the S side and the Gi solve on a second stream),
  * "nt_mode" (lrn_ip_prepare_w: 1 = NT scaling without singular vectors -- Newton-Schulz square roots of K = L_X'SL_X,
  * Lyapunov solve for the second-order term, SVD route as fallback --, 0 = the reference's SVD route always; lrn_prepare_w

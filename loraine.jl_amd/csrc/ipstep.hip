@@ -303,6 +303,25 @@ __global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict_
   lz_fused_body(M, n, nwg, j, do_symv, qmod, Q3, Y2, PA2, ab, qs, sh);
 }
 
+// The same step of TWO independent runs on matrices of one size in one launch: blockIdx.y picks the run (round 4, second
+// session).  The two eigmin searches of a step-length computation used to live on two streams so that their launch chains
+// would overlap; the kernel trace of a maxG11 solve (tools/lz_overlap.py) shows that they do not -- 4 % of the kernel time of
+// the two queues overlaps, a step of either run has the chip to itself for 8-9 us of which it uses a fifth of the CUs.
+// Side by side in one grid a pair of steps costs what one did.
+struct LzPair {
+  const double* M[2];
+  double* Q3[2];
+  double* Y2[2];
+  double* PA2[2];
+  double* ab[2];
+};
+__global__ __launch_bounds__(256) void lz_fused_pair_kernel(LzPair a, int n, int nwg, int j, int do_symv, int qmod) {
+  extern __shared__ double qs[];            // q_j (n doubles)
+  __shared__ double sh[16 * 16 + 8];
+  const int r = blockIdx.y;                 // (uniform: the arrays of the argument block are read with scalar loads)
+  lz_fused_body(a.M[r], n, nwg, j, do_symv, qmod, a.Q3[r], a.Y2[r], a.PA2[r], a.ab[r], qs, sh);
+}
+
 // more than 64 KB of dynamic LDS need the attribute (once per device); false: the two-kernel step is taken
 static bool lz_big_lds_ok() {
   static bool done[64] = {}, ok[64] = {};
@@ -310,6 +329,8 @@ static bool lz_big_lds_ok() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   if (!done[dev]) {
     ok[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(lz_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LZ_FUSED_MAX * 8) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(lz_fused_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LZ_FUSED_MAX * 8) == hipSuccess;
     if (!ok[dev]) (void)hipGetLastError();
     done[dev] = true;
@@ -411,9 +432,9 @@ static double ritz_residual(const std::vector<double>& a, const std::vector<doub
 }
 
 // One Lanczos iteration as a resumable run: batches of 16 steps are queued on the run's stream, the (alpha, beta)
-// pairs come back in one copy per batch and the host decides on the tridiagonal matrix.  Two runs on two streams
-// interleave (eigmin_pair below): a step is two dependent launches of a few microseconds, so two independent
-// chains nearly halve the wall time of the two eigmin calls of a step-length search.
+// pairs come back in one copy per batch and the host decides on the tridiagonal matrix.  The two eigmin calls of a
+// step-length search run side by side: in one launch per pair of steps (eigmin_dev_pair_merged), or, above LZ_FUSED_MAX,
+// as two launch chains on two streams (eigmin_dev_pair).
 struct LzRun {
   const double* M = nullptr;
   int n = 0;
@@ -523,12 +544,16 @@ static int lz_fetch(lrn_ctx* c, LzRun& r) {
 // above 1e-2 of its scale, out of reach of every rule of lz_decide (the Kato-Temple rule needs 1e-3, the plain one 1e-11;
 // the sign-class rule is excluded by theta < 0) -- the next batch is queued before that look.  Timing only: the looks and
 // their verdicts are the same; a batch queued in vain is ignored (eigmin_dev_pair makes c->stream wait for it).
-static void lz_queue_ahead(lrn_ctx* c, LzRun& r) {
+static bool lz_cannot_end_at_next_look(const LzRun& r) {
   static const bool off = getenv("LRN_LZ_NOAHEAD") != nullptr;      // (measurement knob)
-  if (off || r.persist || r.ahead || r.mc >= r.mmax || !(r.err_prev > 0.0) || !(r.err_last > 0.0)) return;
-  if (!(r.theta_prev < 0.0)) return;
+  if (off || r.persist || r.ahead || r.mc >= r.mmax || !(r.err_prev > 0.0) || !(r.err_last > 0.0)) return false;
+  if (!(r.theta_prev < 0.0)) return false;
   const double next = r.err_last * std::min(1.0, r.err_last / r.err_prev);
-  if (!(next > 10.0)) return;
+  return next > 10.0;
+}
+
+static void lz_queue_ahead(lrn_ctx* c, LzRun& r) {
+  if (!lz_cannot_end_at_next_look(r)) return;
   lz_launch(r);                       // (r.m == r.mc: the batch [mc, m1))
   r.ahead = true;
   c->counts["lanczos_ahead"] += 1;
@@ -635,10 +660,80 @@ int eigmin_dev(lrn_ctx* c, const double* M, int n, double* lam, int* steps_out, 
   return LRN_OK;
 }
 
+// ---- two runs in lock-step, one launch per pair of steps (lz_fused_pair_kernel), both on c->stream
+static void lz_launch_pair(LzRun* r) {
+  const int n = r[0].n;
+  const int batch = n <= 16 ? n : 16;
+  const int m0 = r[0].m, m1 = std::min(r[0].mmax, m0 + batch);
+  LzPair a;
+  for (int k = 0; k < 2; ++k) { a.M[k] = r[k].M; a.Q3[k] = r[k].q; a.Y2[k] = r[k].w; a.PA2[k] = r[k].ypart; a.ab[k] = r[k].ab; }
+  const size_t lds = (size_t)n * 8;
+  for (int j = m0; j < m1; ++j)
+    hipLaunchKernelGGL(lz_fused_pair_kernel, dim3(r[0].nwg, 2), dim3(256), lds, r[0].st, a, n, r[0].nwg, j, 1, 3);
+  hipLaunchKernelGGL(lz_fused_pair_kernel, dim3(1, 2), dim3(256), lds, r[0].st, a, n, r[0].nwg, m1, 0, 3);
+  r[0].m1 = r[1].m1 = m1;
+}
+
+static int lz_fetch_pair(lrn_ctx* c, LzRun* r) {
+  const int m1 = r[0].m1;
+  for (int k = 0; k < 2; ++k) {
+    r[k].hab.resize(2 * (size_t)m1);
+    LRN_HIP(c, hipMemcpyAsync(r[k].hab.data(), r[k].ab, (size_t)2 * m1 * 8, hipMemcpyDeviceToHost, r[0].st));
+  }
+  LRN_HIP(c, hipStreamSynchronize(r[0].st));
+  for (int k = 0; k < 2; ++k) { r[k].mc = m1; r[k].m = m1; r[k].ahead = false; }
+  return LRN_OK;
+}
+
+static int eigmin_dev_pair_merged(lrn_ctx* c, const double* M1, const double* M2, int n, double lam[2], bool conv[2],
+                                  double scale[2], bool* taken) {
+  LzRun r[2];
+  LRN_TRY(lz_begin(c, r[0], M1, n, c->stream, c->lzbuf));
+  LRN_TRY(lz_begin(c, r[1], M2, n, c->stream, c->lzbuf2));
+  *taken = r[0].fused && r[1].fused && !r[0].persist && !r[1].persist && r[0].mmax == r[1].mmax;
+  if (!*taken) return LRN_OK;                // (n > LZ_FUSED_MAX or < 32: the two-stream form below)
+  lz_start(r[0]);
+  lz_start(r[1]);
+  while (!r[0].done && !r[1].done) {
+    if (!r[0].ahead) lz_launch_pair(r);
+    LRN_TRY(lz_fetch_pair(c, r));
+    if (lz_cannot_end_at_next_look(r[0]) && lz_cannot_end_at_next_look(r[1])) {
+      lz_launch_pair(r);                     // (queued before the host looks at the batch it has just fetched: lz_queue_ahead)
+      r[0].ahead = r[1].ahead = true;
+      c->counts["lanczos_ahead"] += 1;
+    }
+    LRN_TRY(lz_decide(c, r[0]));
+    LRN_TRY(lz_decide(c, r[1]));
+    c->counts["lanczos_pair_batches"] += 1;
+  }
+  // the longer run goes on alone (a pair batch queued ahead carries its steps [mc, m1) already)
+  for (int k = 0; k < 2; ++k) {
+    while (!r[k].done) {
+      if (!r[k].ahead) lz_launch(r[k]);
+      LRN_TRY(lz_fetch(c, r[k]));
+      lz_queue_ahead(c, r[k]);
+      LRN_TRY(lz_decide(c, r[k]));
+    }
+  }
+  for (int k = 0; k < 2; ++k) {
+    lam[k] = r[k].theta; conv[k] = r[k].conv; scale[k] = r[k].scale;
+    c->counts["lanczos_steps"] += r[k].m;
+    c->counts["lanczos_runs"] += 1;
+  }
+  LRN_HIP(c, hipGetLastError());
+  return LRN_OK;
+}
+
 // The Lanczos runs of two matrices of the same size side by side (second one on c->stream2, which first waits for
-// everything queued on c->stream): results as from two eigmin_dev calls.
+// everything queued on c->stream): results as from two eigmin_dev calls.  Option eigmin_pair = 2 (default): both runs in one
+// launch per step instead (eigmin_dev_pair_merged); 1: this two-stream form.
 static int eigmin_dev_pair(lrn_ctx* c, const double* M1, const double* M2, int n, double lam[2], bool conv[2],
                            double scale[2]) {
+  if (c->opt.eigmin_pair >= 2) {
+    bool taken = false;
+    LRN_TRY(eigmin_dev_pair_merged(c, M1, M2, n, lam, conv, scale, &taken));
+    if (taken) return LRN_OK;
+  }
   if (!c->stream2) LRN_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   LzRun r[2];
   LRN_TRY(lz_begin(c, r[0], M1, n, c->stream, c->lzbuf));

@@ -115,21 +115,24 @@ def test_resident_equals_host_driver(name, opts):
 @pytest.mark.parametrize("name,opts", [("control1", dict(kit=0)), ("maxG11", dict(kit=0, datarank=-1))])
 def test_second_stream_changes_nothing(dev, name, opts):
     """Options "prepw_streams" (S side of prepare_W beside the SVD) and "eigmin_pair" (the two Lanczos runs of a
-    step-length search interleaved): the same kernels on the same data in the same order per buffer -- every
-    iteration's objectives are bit-identical with and without."""
+    step-length search one after the other / as two launch chains on two streams / in lock-step, one launch per pair of
+    steps -- the default): the same arithmetic on the same data in the same order per buffer -- every iteration's
+    objectives are bit-identical in all three forms, and the default does take the paired launches."""
     path = os.path.join(GOLD, f"{name}.dat-s")
     runs = []
-    for on in (0, 1):
-        dev.set_option("prepw_streams", on)
-        dev.set_option("eigmin_pair", on)
+    for streams, pair in ((0, 0), (1, 1), (1, 2)):
+        dev.set_option("prepw_streams", streams)
+        dev.set_option("eigmin_pair", pair)
+        before = dev.count("lanczos_pair_batches")
         try:
             o = _run(path, True, device=dev, **opts)
         finally:
             dev.set_option("prepw_streams", 1)
-            dev.set_option("eigmin_pair", 1)
+            dev.set_option("eigmin_pair", 2)
         assert o.termination_status() == "OPTIMAL"
+        assert (dev.count("lanczos_pair_batches") > before) == (pair == 2)
         runs.append([(t["primal_obj"], t["dual_obj"], t["dimacs"]) for t in o.solver.trace])
-    assert runs[0] == runs[1]
+    assert runs[0] == runs[1] == runs[2]
 
 
 @pytest.mark.parametrize("eig", [1, 2])
