@@ -1,11 +1,17 @@
-"""Per-iteration time breakdown of a resident solve of an SDPA file (gpu_ms phases, find_step, Lyapunov, the rest)."""
+"""Per-iteration time breakdown of a resident solve of an SDPA file (gpu_ms phases, find_step, Lyapunov, the rest).
+
+    python3 tools/iter_breakdown.py maxG11 [key=value,key=value]      # library options (lrn_set_option), e.g. eigmin_pair=1
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, loraine_jl_amd
 from loraine_jl_amd.optimizer import Optimizer
 name = sys.argv[1] if len(sys.argv) > 1 else "maxG11"
 opts = dict(kit=0, datarank=-1) if name == "maxG11" else (dict(kit=1, preconditioner=1, erank=1, eDIMACS=1e-5) if name == "thetaG11" else dict(kit=0))
-o = Optimizer(resident=True); o.set_silent(True)
+dev = loraine_jl_amd.Device(0)
+for kv in filter(None, (sys.argv[2] if len(sys.argv) > 2 else "").split(",")):
+    dev.set_option(kv.split("=")[0], float(kv.split("=")[1]))
+o = Optimizer(device=dev, resident=True); o.set_silent(True)
 for k, v in opts.items(): o.set_attribute(k, v)
 o.read_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", name + ".dat-s"))
 o.optimize()
