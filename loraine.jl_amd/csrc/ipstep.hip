@@ -305,9 +305,11 @@ __global__ __launch_bounds__(256) void lz_fused_kernel(const double* __restrict_
 
 // The same step of TWO independent runs on matrices of one size in one launch: blockIdx.y picks the run (round 4, second
 // session).  The two eigmin searches of a step-length computation used to live on two streams so that their launch chains
-// would overlap; the kernel trace of a maxG11 solve (tools/lz_overlap.py) shows that they do not -- 4 % of the kernel time of
-// the two queues overlaps, a step of either run has the chip to itself for 8-9 us of which it uses a fifth of the CUs.
-// Side by side in one grid a pair of steps costs what one did.
+// overlap.  Under rocprofv3's kernel trace they do not (tools/lz_overlap.py on a maxG11 solve: 4 % of the kernel time of the
+// two queues overlaps); without the profiler both forms take the same time (same box, profiles/r04_lanczos_pair_ab.txt:
+// find_step 4.99 vs 4.96 ms at 480 steps, 0.84 vs 0.90 at 64) -- the chains did overlap, and what a step-length search costs
+// is its LONGER chain at 8-10 us per step.  The paired form is the default all the same: half the launches for the host to
+// issue, one stream, no events between streams.
 struct LzPair {
   const double* M[2];
   double* Q3[2];
