@@ -215,10 +215,6 @@ __global__ __launch_bounds__(1024) void lz_step_kernel(const double* __restrict_
 // and then computes its 16 rows of y_j = M q_j and their share of q_j . y_j.  Vectors rotate through three (q) and two (y)
 // buffers so that nothing a workgroup still reads is overwritten inside a launch.  `do_symv` = 0: only finish step j-1
 // (last launch of a batch: the host needs alpha, beta of every step it reads).
-static int lz_symv_mode(int n) {      // do_symv argument of the step launches: 2 = all loads of a lane in flight (n <= 1024)
-  static const bool off = getenv("LRN_LZ_SHALLOW") != nullptr;      // (measurement knob)
-  return (!off && n <= 1024) ? 2 : 1;
-}
 static constexpr int LZ_FUSED_MAX = 16384;      // (round 4: 4096 -> 16384, q_j in up to 128 KB of LDS: at msz 10^4 the two-kernel
                                                 // step costs 0.21 + 0.24 ms -- its single-workgroup half sums 64 partial vectors)
 __device__ __forceinline__ void lz_fused_body(const double* __restrict__ M, int n, int nwg, int j, int do_symv, int qmod,
@@ -273,22 +269,10 @@ __device__ __forceinline__ void lz_fused_body(const double* __restrict__ M, int 
     const double* m2 = M + (size_t)min(c0 + 2, n - 1) * n;
     const double* m3 = M + (size_t)min(c0 + 3, n - 1) * n;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (do_symv == 2) {
-      // n <= 1024: every load of the lane in flight at once (up to 64; indices beyond n clamped, their q taken as zero) --
-      // one exposed L2 latency instead of four
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int k = lane + 64 * u;
-        const int kk = k < n ? k : n - 1;
-        const double q = k < n ? qs[kk] : 0.0;
-        a0 += m0[kk] * q; a1 += m1[kk] * q; a2 += m2[kk] * q; a3 += m3[kk] * q;
-      }
-    } else {
 #pragma unroll 4
-      for (int k = lane; k < n; k += 64) {
-        const double q = qs[k];
-        a0 += m0[k] * q; a1 += m1[k] * q; a2 += m2[k] * q; a3 += m3[k] * q;
-      }
+    for (int k = lane; k < n; k += 64) {
+      const double q = qs[k];
+      a0 += m0[k] * q; a1 += m1[k] * q; a2 += m2[k] * q; a3 += m3[k] * q;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -410,7 +394,7 @@ int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int q
   const int nwg = (n + 15) / 16;
   const size_t lds = (size_t)n * 8;
   for (int j = j0; j < j1; ++j)
-    hipLaunchKernelGGL(lz_fused_kernel, dim3(nwg), dim3(256), lds, st, M, n, nwg, j, lz_symv_mode(n), qcap, Q, Y2, PA2, ab);
+    hipLaunchKernelGGL(lz_fused_kernel, dim3(nwg), dim3(256), lds, st, M, n, nwg, j, 1, qcap, Q, Y2, PA2, ab);
   hipLaunchKernelGGL(lz_fused_kernel, dim3(1), dim3(256), lds, st, M, n, nwg, j1, 0, qcap, Q, Y2, PA2, ab);
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }
@@ -519,7 +503,7 @@ static void lz_launch(LzRun& r) {
   if (r.fused) {
     const size_t lds = (size_t)r.n * 8;
     for (int j = r.m; j < r.m1; ++j)
-      hipLaunchKernelGGL(lz_fused_kernel, dim3(r.nwg), dim3(256), lds, r.st, r.M, r.n, r.nwg, j, lz_symv_mode(r.n), 3, r.q, r.w, r.ypart, r.ab);
+      hipLaunchKernelGGL(lz_fused_kernel, dim3(r.nwg), dim3(256), lds, r.st, r.M, r.n, r.nwg, j, 1, 3, r.q, r.w, r.ypart, r.ab);
     hipLaunchKernelGGL(lz_fused_kernel, dim3(1), dim3(256), lds, r.st, r.M, r.n, r.nwg, r.m1, 0, 3, r.q, r.w, r.ypart, r.ab);
     return;
   }
@@ -687,7 +671,7 @@ static void lz_launch_pair(LzRun* r) {
   for (int k = 0; k < 2; ++k) { a.M[k] = r[k].M; a.Q3[k] = r[k].q; a.Y2[k] = r[k].w; a.PA2[k] = r[k].ypart; a.ab[k] = r[k].ab; }
   const size_t lds = (size_t)n * 8;
   for (int j = m0; j < m1; ++j)
-    hipLaunchKernelGGL(lz_fused_pair_kernel, dim3(r[0].nwg, 2), dim3(256), lds, r[0].st, a, n, r[0].nwg, j, lz_symv_mode(n), 3);
+    hipLaunchKernelGGL(lz_fused_pair_kernel, dim3(r[0].nwg, 2), dim3(256), lds, r[0].st, a, n, r[0].nwg, j, 1, 3);
   hipLaunchKernelGGL(lz_fused_pair_kernel, dim3(1, 2), dim3(256), lds, r[0].st, a, n, r[0].nwg, m1, 0, 3);
   r[0].m1 = r[1].m1 = m1;
 }
