@@ -117,6 +117,7 @@ int lrn_set_option(lrn_ctx* c, const char* key, double value) {
   else if (!strcmp(key, "jacobi_cross")) c->opt.jacobi_cross = (int)value;
   else if (!strcmp(key, "jacobi_early")) c->opt.jacobi_early = value;
   else if (!strcmp(key, "eigmin_pair")) c->opt.eigmin_pair = (int)value;
+  else if (!strcmp(key, "lz_resident")) c->opt.lz_resident = (int)value;
   else if (!strcmp(key, "prepw_streams")) c->opt.prepw_streams = (int)value;
   else if (!strcmp(key, "jacobi_warm")) c->opt.jacobi_warm = value != 0.0;
   else if (!strcmp(key, "nt_mode")) c->opt.nt_mode = (int)value;

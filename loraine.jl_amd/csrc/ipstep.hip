@@ -385,6 +385,165 @@ __global__ __launch_bounds__(256) void lz_fused_multi_kernel(const double* __res
   if (blockIdx.x == 0) lz_fused_body(M, n, nwg, j1, 0, qmod, Q3, Y2, PA2, ab, qs, sh);      // finish step j1 - 1
 }
 
+// ---- RESIDENT steps, second form (round 4, second session; option lz_resident).  What made the kernel above slower than
+// one launch per step is not the barrier but its two device-scope fences (tools/lab/xcd_barrier.hip,
+// profiles/r04_xcd_barrier.txt: a barrier of 51 workgroups with an 801-vector exchanged costs 4.7 us per step with
+// __threadfence() on both sides and 2.3 us when counter AND payload travel as relaxed agent-scope atomics -- they bypass the
+// L1s and meet at the coherent level, nothing has to be written back or invalidated), and that every step still re-read its
+// 16 columns of M and three vectors from L2.  Here, for n <= 1024:
+//  * a workgroup keeps its 16 columns of M in REGISTERS for the whole launch (wave w: columns 4 w .. 4 w + 3, lane l: rows
+//    l, l + 64, ...: the order in which lz_fused_body sums them) and q_j, q_{j-1}, q_{j-2} in LDS;
+//  * the only data other workgroups produce -- the 16 entries of y_j and the partial sum of q_j . y_j per workgroup -- are
+//    written and read with relaxed agent-scope atomic stores / loads; beta_{j-1} stays in a register;
+//  * the barrier is a relaxed counter; every spin is bounded by the wall clock and an abort word, as above.
+// The arithmetic, operation by operation, is lz_fused_body's: same coefficients bit for bit
+// (test_resident_lanczos_steps_are_the_launched_ones).  blockIdx.y: the run (two runs of a step-length search in lock-step).
+struct LzRes {
+  const double* M;
+  double* Q3;
+  double* Y2;
+  double* PA2;
+  double* ab;
+  unsigned* flag;
+  unsigned base;
+};
+struct LzResPair { LzRes r[2]; };
+
+__device__ __forceinline__ double lz_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lz_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool lz_barrier_relaxed(unsigned* flag, unsigned target, long long limit, int* ok_s) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomic stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (wall_clock64() - t0 > limit) {
+        __hip_atomic_store(flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *ok_s = ok;
+  }
+  __syncthreads();
+  return *ok_s != 0;
+}
+
+static constexpr int LZ_RES_MAX = 1024;       // 16 rows per lane and column
+__global__ __launch_bounds__(256) void lz_resident_kernel(LzResPair args, int n, int nwg, int j0, int j1, int qmod, long long limit) {
+  extern __shared__ double ql[];            // three n-vectors: q_j, q_{j-1}, q_{j-2} rotate through them
+  __shared__ double sh[16 * 16 + 8];
+  __shared__ int ok_s;
+  const LzRes& R = args.r[blockIdx.y];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int c0 = blockIdx.x * 16 + 4 * w;
+  constexpr int U = LZ_RES_MAX / 64;
+  double mreg[4][U];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    const double* col = R.M + (size_t)min(c0 + cc, n - 1) * n;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = lane + 64 * u;
+      mreg[cc][u] = k < n ? col[k] : 0.0;
+    }
+  }
+  // state of the recurrence at entry: q_{j0-1}, q_{j0-2} (the ring of the previous launches), beta_{j0-2}
+  double bprev = 0.0;
+  if (j0 > 0) {
+    const double* g1 = R.Q3 + (size_t)((j0 - 1) % qmod) * n;
+    double* l1 = ql + (size_t)((j0 - 1) % 3) * n;
+    for (int i = t; i < n; i += 256) l1[i] = g1[i];
+    if (j0 > 1) {
+      const double* g2 = R.Q3 + (size_t)((j0 - 2) % qmod) * n;
+      double* l2 = ql + (size_t)((j0 - 2) % 3) * n;
+      for (int i = t; i < n; i += 256) l2[i] = g2[i];
+      bprev = R.ab[2 * (j0 - 2) + 1];
+    }
+  }
+  __syncthreads();
+  unsigned target = R.base;
+  for (int j = j0; j <= j1; ++j) {
+    const bool finish = j == j1;            // (workgroup 0 only: alpha, beta of step j1 - 1 and q_{j1} for the host and the next launch)
+    if (finish && blockIdx.x != 0) break;
+    double* qs = ql + (size_t)(j % 3) * n;
+    double* qj = R.Q3 + (size_t)(j % qmod) * n;
+    if (j == 0) {
+      for (int i = t; i < n; i += 256) qs[i] = qj[i];
+    } else {
+      const double* qm1 = ql + (size_t)((j - 1) % 3) * n;
+      const double* qm2 = ql + (size_t)((j > 1 ? j - 2 : 0) % 3) * n;
+      const double* ym1 = R.Y2 + (size_t)((j + 1) & 1) * n;
+      const double* pa = R.PA2 + (size_t)((j + 1) & 1) * nwg;
+      double a = 0.0;
+      for (int e = t; e < nwg; e += 256) a += lz_ld(pa + e);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+      if ((t & 63) == 0) sh[t >> 6] = a;
+      __syncthreads();
+      const double alpha = sh[0] + sh[1] + sh[2] + sh[3];
+      __syncthreads();
+      double b2 = 0.0;
+      for (int i = t; i < n; i += 256) {
+        const double v = lz_ld(ym1 + i) - alpha * qm1[i] - (j > 1 ? bprev * qm2[i] : 0.0);
+        qs[i] = v;
+        b2 += v * v;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) b2 += __shfl_down(b2, off, 64);
+      if ((t & 63) == 0) sh[t >> 6] = b2;
+      __syncthreads();
+      const double beta = sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
+      const double r = beta > 0.0 ? 1.0 / beta : 0.0;
+      for (int i = t; i < n; i += 256) {
+        const double v = qs[i] * r;
+        qs[i] = v;
+        if (blockIdx.x == 0) qj[i] = v;
+      }
+      if (blockIdx.x == 0 && t == 0) { R.ab[2 * (j - 1)] = alpha; R.ab[2 * (j - 1) + 1] = beta; }
+      bprev = beta;
+    }
+    __syncthreads();
+    if (finish) break;
+    {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = lane + 64 * u;
+        if (k < n) {
+          const double q = qs[k];
+          a0 += mreg[0][u] * q; a1 += mreg[1][u] * q; a2 += mreg[2][u] * q; a3 += mreg[3][u] * q;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off, 64); a1 += __shfl_down(a1, off, 64);
+        a2 += __shfl_down(a2, off, 64); a3 += __shfl_down(a3, off, 64);
+      }
+      if (lane == 0) { sh[4 * w + 0] = a0; sh[4 * w + 1] = a1; sh[4 * w + 2] = a2; sh[4 * w + 3] = a3; }
+    }
+    __syncthreads();
+    if (t < 16) {
+      const double y = sh[t];
+      const int ii = blockIdx.x * 16 + t;
+      double d = 0.0;
+      if (ii < n) {
+        lz_st(R.Y2 + (size_t)(j & 1) * n + ii, y);
+        d = qs[ii] * y;
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) d += __shfl_down(d, off, 16);
+      if (t == 0) lz_st(R.PA2 + (size_t)(j & 1) * nwg + blockIdx.x, d);
+    }
+    target += (unsigned)nwg;
+    if (!lz_barrier_relaxed(R.flag, target, limit, &ok_s)) return;
+  }
+}
+
 // steps [j0, j1) of the single-launch Lanczos recurrence with every q_j kept (Q: (j1 + 1) x n doubles, q_0 = unit start
 // vector in Q[0..n)), then the finishing launch: alpha_j, beta_j of all steps < j1 are in ab, q_{j1} in Q.  For
 // lanczos.hip (preconditioner setup); n <= LZ_FUSED_MAX.
@@ -453,6 +612,7 @@ struct LzRun {
   bool fused = false;                       // lz_fused_kernel: Q3 = q (3 n), Y2 = w (2 n), PA2 = ypart (2 nwg)
   int nwg = 0;
   bool persist = false;                     // lz_fused_multi_kernel: a batch of steps per launch
+  bool resident = false;                    // lz_resident_kernel: the same, M in registers, relaxed-atomic exchange (option lz_resident)
   unsigned* flag = nullptr;                 // its barrier counter and abort word
   unsigned bar_base = 0;                    // barriers passed so far x nwg
 };
@@ -478,6 +638,7 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   // barrier -- device-scope release / acquire across eight L2s -- costs more than a launch: maxG11 find_step 1.0 -> 1.25 ms)
   static const bool persist_on = getenv("LRN_LZ_PERSIST") && atoi(getenv("LRN_LZ_PERSIST")) != 0;
   r.persist = r.fused && persist_on && !c->lz_no_persist && r.nwg <= 256 && (size_t)n * 8 <= 60 * 1024;
+  r.resident = r.fused && !r.persist && c->opt.lz_resident != 0 && !c->lz_no_persist && n <= LZ_RES_MAX;
   r.flag = reinterpret_cast<unsigned*>(r.ab + 2 * (size_t)r.mmax + 8);      // (inside the 64 doubles of slack)
   r.bar_base = 0;
   return LRN_OK;
@@ -485,7 +646,7 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
 
 // start vector (after lz_begin; a fresh workspace is zeroed on c->stream, which r.st must have waited for)
 static void lz_start(LzRun& r) {
-  if (r.persist) (void)hipMemsetAsync(r.flag, 0, 16, r.st);
+  if (r.persist || r.resident) (void)hipMemsetAsync(r.flag, 0, 16, r.st);
   r.bar_base = 0;
   hipLaunchKernelGGL(lz_init_kernel, dim3((r.n + 255) / 256), dim3(256), 0, r.st, r.q, r.n);
   hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, r.st, r.ypart, r.nchunk, r.n, -1, r.q, r.qprev, r.w, r.ab);
@@ -494,6 +655,14 @@ static void lz_start(LzRun& r) {
 static void lz_launch(LzRun& r) {
   const int batch = r.n <= 16 ? r.n : 16;
   r.m1 = std::min(r.mmax, r.m + batch);
+  if (r.resident) {
+    LzResPair a;
+    a.r[0] = LzRes{r.M, r.q, r.w, r.ypart, r.ab, r.flag, r.bar_base};
+    a.r[1] = a.r[0];
+    hipLaunchKernelGGL(lz_resident_kernel, dim3(r.nwg, 1), dim3(256), (size_t)3 * r.n * 8, r.st, a, r.n, r.nwg, r.m, r.m1, 3, 2000000LL);
+    r.bar_base += (unsigned)(r.m1 - r.m) * (unsigned)r.nwg;
+    return;
+  }
   if (r.fused && r.persist) {
     hipLaunchKernelGGL(lz_fused_multi_kernel, dim3(r.nwg), dim3(256), (size_t)r.n * 8, r.st, r.M, r.n, r.nwg, r.m, r.m1, 3, r.q,
                        r.w, r.ypart, r.ab, r.flag, r.bar_base, 2000000LL);          // limit: 20 ms at 100 MHz
@@ -519,14 +688,15 @@ static int lz_fetch(lrn_ctx* c, LzRun& r) {
   r.hab.resize(2 * (size_t)m1);
   LRN_HIP(c, hipMemcpyAsync(r.hab.data(), r.ab, (size_t)2 * m1 * 8, hipMemcpyDeviceToHost, r.st));
   unsigned fl[2] = {0u, 0u};
-  if (r.persist) LRN_HIP(c, hipMemcpyAsync(fl, r.flag, 8, hipMemcpyDeviceToHost, r.st));
+  if (r.persist || r.resident) LRN_HIP(c, hipMemcpyAsync(fl, r.flag, 8, hipMemcpyDeviceToHost, r.st));
   LRN_HIP(c, hipStreamSynchronize(r.st));
-  if (r.persist && fl[1] != 0u) {
+  if ((r.persist || r.resident) && fl[1] != 0u) {
     // the resident workgroups did not all meet in time (see lz_fused_multi_kernel): from now on one launch per step on
     // this context, and this run again from its start vector
     c->lz_no_persist = true;
     c->counts["lz_persist_abort"] += 1;
     r.persist = false;
+    r.resident = false;
     r.m = 0; r.have_prev = false; r.scale = 0.0;
     r.err_prev = r.err_last = 0.0;
     lz_start(r);
@@ -669,6 +839,14 @@ static void lz_launch_pair(LzRun* r) {
   const int m0 = r[0].m, m1 = std::min(r[0].mmax, m0 + batch);
   LzPair a;
   for (int k = 0; k < 2; ++k) { a.M[k] = r[k].M; a.Q3[k] = r[k].q; a.Y2[k] = r[k].w; a.PA2[k] = r[k].ypart; a.ab[k] = r[k].ab; }
+  if (r[0].resident && r[1].resident) {
+    LzResPair ra;
+    for (int k = 0; k < 2; ++k) ra.r[k] = LzRes{r[k].M, r[k].q, r[k].w, r[k].ypart, r[k].ab, r[k].flag, r[k].bar_base};
+    hipLaunchKernelGGL(lz_resident_kernel, dim3(r[0].nwg, 2), dim3(256), (size_t)3 * n * 8, r[0].st, ra, n, r[0].nwg, m0, m1, 3, 2000000LL);
+    for (int k = 0; k < 2; ++k) r[k].bar_base += (unsigned)(m1 - m0) * (unsigned)r[k].nwg;
+    r[0].m1 = r[1].m1 = m1;
+    return;
+  }
   const size_t lds = (size_t)n * 8;
   for (int j = m0; j < m1; ++j)
     hipLaunchKernelGGL(lz_fused_pair_kernel, dim3(r[0].nwg, 2), dim3(256), lds, r[0].st, a, n, r[0].nwg, j, 1, 3);
@@ -676,13 +854,17 @@ static void lz_launch_pair(LzRun* r) {
   r[0].m1 = r[1].m1 = m1;
 }
 
-static int lz_fetch_pair(lrn_ctx* c, LzRun* r) {
+static int lz_fetch_pair(lrn_ctx* c, LzRun* r, bool* aborted) {
   const int m1 = r[0].m1;
+  unsigned fl[2][2] = {{0u, 0u}, {0u, 0u}};
   for (int k = 0; k < 2; ++k) {
     r[k].hab.resize(2 * (size_t)m1);
     LRN_HIP(c, hipMemcpyAsync(r[k].hab.data(), r[k].ab, (size_t)2 * m1 * 8, hipMemcpyDeviceToHost, r[0].st));
+    if (r[k].resident) LRN_HIP(c, hipMemcpyAsync(fl[k], r[k].flag, 8, hipMemcpyDeviceToHost, r[0].st));
   }
   LRN_HIP(c, hipStreamSynchronize(r[0].st));
+  *aborted = fl[0][1] != 0u || fl[1][1] != 0u;      // a resident launch gave up at a barrier: the caller starts over, launched
+  if (*aborted) return LRN_OK;
   for (int k = 0; k < 2; ++k) { r[k].mc = m1; r[k].m = m1; r[k].ahead = false; }
   return LRN_OK;
 }
@@ -698,7 +880,13 @@ static int eigmin_dev_pair_merged(lrn_ctx* c, const double* M1, const double* M2
   lz_start(r[1]);
   while (!r[0].done && !r[1].done) {
     if (!r[0].ahead) lz_launch_pair(r);
-    LRN_TRY(lz_fetch_pair(c, r));
+    bool aborted = false;
+    LRN_TRY(lz_fetch_pair(c, r, &aborted));
+    if (aborted) {
+      c->lz_no_persist = true;               // (lz_begin: no resident launches on this context from now on)
+      c->counts["lz_persist_abort"] += 1;
+      return eigmin_dev_pair_merged(c, M1, M2, n, lam, conv, scale, taken);
+    }
     if (lz_cannot_end_at_next_look(r[0]) && lz_cannot_end_at_next_look(r[1])) {
       lz_launch_pair(r);                     // (queued before the host looks at the batch it has just fetched: lz_queue_ahead)
       r[0].ahead = r[1].ahead = true;
@@ -707,6 +895,7 @@ static int eigmin_dev_pair_merged(lrn_ctx* c, const double* M1, const double* M2
     LRN_TRY(lz_decide(c, r[0]));
     LRN_TRY(lz_decide(c, r[1]));
     c->counts["lanczos_pair_batches"] += 1;
+    if (r[0].resident && r[1].resident) c->counts["lanczos_resident_batches"] += 1;
   }
   // the longer run goes on alone (a pair batch queued ahead carries its steps [mc, m1) already)
   for (int k = 0; k < 2; ++k) {

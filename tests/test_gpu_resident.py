@@ -46,6 +46,30 @@ def test_lanczos_eigmin(dev, n, kind):
         assert (got > -1e-6) == (ref > -1e-6), (got, ref, steps)
 
 
+@pytest.mark.parametrize("n", [64, 333, 801, 1024])
+def test_resident_lanczos_steps_are_the_launched_ones(dev, n):
+    """Option "lz_resident": 16 Lanczos steps per launch (the workgroup's columns of M in registers, y and the partial dot
+    products exchanged through relaxed agent-scope atomics, a relaxed counter as the barrier) against one launch per step:
+    the same operations in the same order -- Ritz value and step count equal bit for bit, on spectra that take 30 to 400
+    steps, and no launch gives up at a barrier."""
+    rng = np.random.default_rng(7 * n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    for lam in (rng.standard_normal(n), np.concatenate([[-1.0], -1.0 + 1e-3 * rng.random(n // 4), np.linspace(0.5, 40.0, n - 1 - n // 4)])):
+        M = (Q * lam) @ Q.T
+        M = (M + M.T) / 2
+        out = []
+        aborts = dev.count("lz_persist_abort")
+        for res in (0, 1):
+            dev.set_option("lz_resident", res)
+            try:
+                out.append(dev.dbg_eigmin(M))
+            finally:
+                dev.set_option("lz_resident", 1)
+        assert dev.count("lz_persist_abort") == aborts
+        assert out[0] == out[1], out
+        assert out[0][1] >= 16
+
+
 def _run(path, resident, device=None, **opts):
     from loraine_jl_amd.optimizer import Optimizer
     o = Optimizer(resident=resident, device=device)        # (options are per context: pass the configured one)
@@ -114,26 +138,34 @@ def test_resident_equals_host_driver(name, opts):
 
 @pytest.mark.parametrize("name,opts", [("control1", dict(kit=0)), ("maxG11", dict(kit=0, datarank=-1))])
 def test_second_stream_changes_nothing(dev, name, opts):
-    """Options "prepw_streams" (S side of prepare_W beside the SVD) and "eigmin_pair" (the two Lanczos runs of a
-    step-length search one after the other / as two launch chains on two streams / in lock-step, one launch per pair of
-    steps -- the default): the same arithmetic on the same data in the same order per buffer -- every iteration's
-    objectives are bit-identical in all three forms, and the default does take the paired launches."""
+    """Options "prepw_streams" (S side of prepare_W beside the SVD), "eigmin_pair" (the two Lanczos runs of a step-length
+    search one after the other / as two launch chains on two streams / in lock-step, one launch per pair of steps) and
+    "lz_resident" (16 Lanczos steps per launch: M in registers, the workgroups exchange y and the partial dot products
+    through relaxed agent-scope atomics and meet at a relaxed counter): the same arithmetic on the same data in the same
+    order -- every iteration's objectives are bit-identical in all forms, and the forms are really taken."""
     path = os.path.join(GOLD, f"{name}.dat-s")
     runs = []
-    for streams, pair in ((0, 0), (1, 1), (1, 2)):
+    default_res = 1
+    for streams, pair, res in ((0, 0, 0), (1, 1, 0), (1, 2, 0), (1, 2, 1), (1, 1, 1)):
         dev.set_option("prepw_streams", streams)
         dev.set_option("eigmin_pair", pair)
+        dev.set_option("lz_resident", res)
         before = dev.count("lanczos_pair_batches")
+        before_res = dev.count("lanczos_resident_batches")
+        aborts = dev.count("lz_persist_abort")
         try:
             o = _run(path, True, device=dev, **opts)
         finally:
             dev.set_option("prepw_streams", 1)
             dev.set_option("eigmin_pair", 2)
+            dev.set_option("lz_resident", default_res)
         assert o.termination_status() == "OPTIMAL"
+        assert dev.count("lz_persist_abort") == aborts          # no resident launch gave up at a barrier
         if name == "maxG11":                 # (control1: blocks of side 10 and 5, below the single-launch step kernel)
             assert (dev.count("lanczos_pair_batches") > before) == (pair == 2)
+            assert (dev.count("lanczos_resident_batches") > before_res) == (pair == 2 and res == 1)
         runs.append([(t["primal_obj"], t["dual_obj"], t["dimacs"]) for t in o.solver.trace])
-    assert runs[0] == runs[1] == runs[2]
+    assert all(r == runs[0] for r in runs[1:])
 
 
 @pytest.mark.parametrize("eig", [1, 2])
