@@ -65,7 +65,7 @@ def test_resident_lanczos_steps_are_the_launched_ones(dev, n):
                 out.append(dev.dbg_eigmin(M))
             finally:
                 dev.set_option("lz_resident", 1)
-        assert dev.count("lz_persist_abort") == aborts
+        assert dev.count("lz_persist_abort") == aborts          # (a launch that gives up sends the run back to launched steps)
         assert out[0] == out[1], out
         assert out[0][1] >= 16
 
@@ -150,9 +150,6 @@ def test_second_stream_changes_nothing(dev, name, opts):
         dev.set_option("prepw_streams", streams)
         dev.set_option("eigmin_pair", pair)
         dev.set_option("lz_resident", res)
-        before = dev.count("lanczos_pair_batches")
-        before_res = dev.count("lanczos_resident_batches")
-        aborts = dev.count("lz_persist_abort")
         try:
             o = _run(path, True, device=dev, **opts)
         finally:
@@ -160,10 +157,11 @@ def test_second_stream_changes_nothing(dev, name, opts):
             dev.set_option("eigmin_pair", 2)
             dev.set_option("lz_resident", default_res)
         assert o.termination_status() == "OPTIMAL"
-        assert dev.count("lz_persist_abort") == aborts          # no resident launch gave up at a barrier
+        # (the counters are those of the last IP iteration: the solver's trace takes and resets them)
+        assert dev.count("lz_persist_abort") == 0               # no resident launch gave up at a barrier ...
         if name == "maxG11":                 # (control1: blocks of side 10 and 5, below the single-launch step kernel)
-            assert (dev.count("lanczos_pair_batches") > before) == (pair == 2)
-            assert (dev.count("lanczos_resident_batches") > before_res) == (pair == 2 and res == 1)
+            assert (dev.count("lanczos_pair_batches") > 0) == (pair == 2)
+            assert (dev.count("lanczos_resident_batches") > 0) == (pair == 2 and res == 1)      # ... and none had before
         runs.append([(t["primal_obj"], t["dual_obj"], t["dimacs"]) for t in o.solver.trace])
     assert all(r == runs[0] for r in runs[1:])
 
