@@ -95,7 +95,7 @@ struct LrnOptions {
   int jacobi_block = 0;           // column block width: 0 auto (32 for n >= 5000), 16, 32
   int jacobi_cross = 1;           // block Jacobi: cross-pair rotations only outside round 0 of a sweep
   int prepw_streams = 1;          // prepare_W: the S side and the Gi solve on a second stream beside cholesky(X) / the SVD / the GEMMs
-  int lz_resident = 0;            // Lanczos steps of the eigmin searches (n <= 1024) as resident launches of 16 steps: M in registers, relaxed-atomic exchange
+  int lz_resident = 1;            // Lanczos steps of the eigmin searches (n <= 1024) as resident launches of 16 steps: M in registers, relaxed-atomic exchange
   int eigmin_pair = 2;            // the two eigmin calls of a step-length search: 2 = one launch per pair of Lanczos steps, 1 = two streams, 0 = one after the other
   double jacobi_early = 3e-8;     // a sweep whose rotated column pairs were all closer to orthogonal than this ends the SVD
   bool jacobi_warm = true;

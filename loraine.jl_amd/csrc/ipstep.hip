@@ -479,6 +479,13 @@ __global__ __launch_bounds__(256) void lz_resident_kernel(LzResPair args, int n,
       const double* qm2 = ql + (size_t)((j > 1 ? j - 2 : 0) % 3) * n;
       const double* ym1 = R.Y2 + (size_t)((j + 1) & 1) * n;
       const double* pa = R.PA2 + (size_t)((j + 1) & 1) * nwg;
+      // (the entries of y_{j-1} requested together with the partial sums: one trip to the coherent level, not two)
+      double yv[LZ_RES_MAX / 256];
+#pragma unroll
+      for (int u = 0; u < LZ_RES_MAX / 256; ++u) {
+        const int i = t + 256 * u;
+        yv[u] = i < n ? lz_ld(ym1 + i) : 0.0;
+      }
       double a = 0.0;
       for (int e = t; e < nwg; e += 256) a += lz_ld(pa + e);
 #pragma unroll
@@ -488,10 +495,14 @@ __global__ __launch_bounds__(256) void lz_resident_kernel(LzResPair args, int n,
       const double alpha = sh[0] + sh[1] + sh[2] + sh[3];
       __syncthreads();
       double b2 = 0.0;
-      for (int i = t; i < n; i += 256) {
-        const double v = lz_ld(ym1 + i) - alpha * qm1[i] - (j > 1 ? bprev * qm2[i] : 0.0);
-        qs[i] = v;
-        b2 += v * v;
+#pragma unroll
+      for (int u = 0; u < LZ_RES_MAX / 256; ++u) {
+        const int i = t + 256 * u;
+        if (i < n) {
+          const double v = yv[u] - alpha * qm1[i] - (j > 1 ? bprev * qm2[i] : 0.0);
+          qs[i] = v;
+          b2 += v * v;
+        }
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) b2 += __shfl_down(b2, off, 64);
@@ -555,6 +566,23 @@ int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int q
   for (int j = j0; j < j1; ++j)
     hipLaunchKernelGGL(lz_fused_kernel, dim3(nwg), dim3(256), lds, st, M, n, nwg, j, 1, qcap, Q, Y2, PA2, ab);
   hipLaunchKernelGGL(lz_fused_kernel, dim3(1), dim3(256), lds, st, M, n, nwg, j1, 0, qcap, Q, Y2, PA2, ab);
+  return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
+}
+
+// the same steps as ONE resident launch (lz_resident_kernel; n <= LZ_RES_MAX): flag = two zeroed words of the caller's
+// workspace (barrier counter, abort word), *base = barriers passed so far x workgroups (the caller keeps it across batches)
+bool lz_resident_ok(const lrn_ctx* c, int n) {
+  return c->opt.lz_resident != 0 && !c->lz_no_persist && n <= LZ_RES_MAX && n >= 32;
+}
+int lz_resident_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
+                      double* ab, unsigned* flag, unsigned* base) {
+  if (n > LZ_RES_MAX || j1 + 1 > qcap || qcap < 3) return LRN_ERR_ARG;
+  const int nwg = (n + 15) / 16;
+  LzResPair a;
+  a.r[0] = LzRes{M, Q, Y2, PA2, ab, flag, *base};
+  a.r[1] = a.r[0];
+  hipLaunchKernelGGL(lz_resident_kernel, dim3(nwg, 1), dim3(256), (size_t)3 * n * 8, st, a, n, nwg, j0, j1, qcap, 2000000LL);
+  *base += (unsigned)(j1 - j0) * (unsigned)nwg;
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }
 

@@ -196,6 +196,16 @@ static int lanczos_extremes_plain(lrn_ctx* c, const double* M, int n, int k, dou
   double* Sdev = ab + 2 * (size_t)mmax + 8;
   hipLaunchKernelGGL(lx_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Q, n, 0u);
   hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, Q, n, -1, Q, ab);
+  // resident launches (ipstep.hip, lz_resident_kernel): a batch of steps per launch; two words of the workspace's slack
+  // are its barrier counter and abort word
+  const bool resident = lz_resident_ok(c, n);
+  unsigned* flag = reinterpret_cast<unsigned*>(Sdev + mmax + 8);
+  unsigned bar_base = 0;
+  if (resident) LRN_HIP(c, hipMemsetAsync(flag, 0, 16, st));
+  auto steps = [&](int j0, int j1) -> int {
+    if (resident) return lz_resident_steps(st, M, n, j0, j1, mmax + 2, Q, Y2, PA2, ab, flag, &bar_base);
+    return lz_fused_steps(st, M, n, j0, j1, mmax + 2, Q, Y2, PA2, ab);
+  };
   std::vector<double> a, b, hab, s_top, s_min;
   double th_top = 0.0, th_min = 0.0;
   // T of a batch is a leading block of the next one's: its extreme eigenvalues bound the next ones (from below / above)
@@ -214,17 +224,26 @@ static int lanczos_extremes_plain(lrn_ctx* c, const double* M, int n, int k, dou
   while (!done && m < mmax) {
     const int m1 = std::min(mmax, m + 24);
     if (queued < m1) {
-      LRN_TRY(lz_fused_steps(st, M, n, queued, m1, mmax + 2, Q, Y2, PA2, ab));
+      LRN_TRY(steps(queued, m1));
       queued = m1;
     }
     m = m1;
     hab.resize(2 * (size_t)m);
     LRN_TRY(copy_out(c, hab.data(), ab, (size_t)2 * m * 8));      // (returns when the batch [.., m) has run)
+    if (resident) {
+      unsigned fl[2] = {0u, 0u};
+      LRN_TRY(copy_out(c, fl, flag, 8));
+      if (fl[1] != 0u) {             // a resident launch gave up at a barrier: launched steps on this context from now on,
+        c->lz_no_persist = true;     // and this setup through the caller's full version
+        c->counts["lz_persist_abort"] += 1;
+        return LRN_OK;
+      }
+    }
     if (!no_spec && queued == m && m < mmax && err_prev > 0.0 && err_last > 0.0) {
       const double next = err_last * std::min(1.0, err_last / err_prev);
       if (next > 100.0) {
         const int m2 = std::min(mmax, m + 24);
-        LRN_TRY(lz_fused_steps(st, M, n, m, m2, mmax + 2, Q, Y2, PA2, ab));
+        LRN_TRY(steps(m, m2));
         queued = m2;
         c->counts["lanczos_plain_ahead"] += 1;
       }

@@ -191,6 +191,30 @@ def test_lanczos_extremes(dev, n, k):
     assert np.allclose(U.T @ U, np.eye(k), atol=1e-10)
 
 
+@pytest.mark.parametrize("n", [600, 801])
+def test_lanczos_extremes_resident_steps_are_the_launched_ones(dev, n):
+    """The plain-recurrence route of the H_alpha setup (k = 1) with resident launches of 24 steps (option lz_resident,
+    default) and with one launch per step: same Ritz values, same Ritz vector, same step count, bit for bit -- also on a
+    spectrum whose low end is a cluster (the 240-step cap of the route, late in thetaG11)."""
+    rng = np.random.default_rng(n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    for lam in (np.concatenate([np.exp(rng.uniform(np.log(1e-3), np.log(1.0), n - 1)), [2.0e4]]),
+                np.concatenate([0.0132 * (1.0 + 3e-4 * np.arange(n // 3)), np.exp(rng.standard_normal(n - n // 3 - 2)) * 0.3, [39.3, 33694.0]])):
+        W = (Q * lam) @ Q.T
+        W = 0.5 * (W + W.T)
+        out = []
+        for res in (0, 1):
+            dev.set_option("lz_resident", res)
+            try:
+                out.append(dev.dbg_lanczos(W, 1))
+            finally:
+                dev.set_option("lz_resident", 1)
+        assert dev.count("lz_persist_abort") == 0
+        (lt0, U0, lmin0, tr0, st0), (lt1, U1, lmin1, tr1, st1) = out
+        assert st0 == st1 and lmin0 == lmin1 and tr0 == tr1
+        assert np.array_equal(lt0, lt1) and np.array_equal(U0, U1)
+
+
 def test_lanczos_invariant_subspace_restart(dev):
     """W = c I at the initial point (Solvers.jl:448-460): every Krylov space is 1-dimensional."""
     lt, U, lmin, tr, steps = dev.dbg_lanczos(3.0 * np.eye(50), 2)
