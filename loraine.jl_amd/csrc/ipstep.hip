@@ -395,42 +395,35 @@ __global__ __launch_bounds__(256) void lz_fused_multi_kernel(const double* __res
 //    l, l + 64, ...: the order in which lz_fused_body sums them) and q_j, q_{j-1}, q_{j-2} in LDS;
 //  * the only data other workgroups produce -- the 16 entries of y_j and the partial sum of q_j . y_j per workgroup -- are
 //    written and read with relaxed agent-scope atomic stores / loads; beta_{j-1} stays in a register;
-//  * the barrier is a relaxed counter; every spin is bounded by the wall clock and an abort word, as above.
+//  * there is no barrier at all: a word that has not been written yet holds a mark, and a reader polls the 17 words of every
+//    workgroup until no mark is left (LZ_MARK_BITS below); every poll loop is bounded by the wall clock and an abort word.
 // The arithmetic, operation by operation, is lz_fused_body's: same coefficients bit for bit
 // (test_resident_lanczos_steps_are_the_launched_ones).  blockIdx.y: the run (two runs of a step-length search in lock-step).
 struct LzRes {
   const double* M;
   double* Q3;
-  double* Y2;
-  double* PA2;
+  double* Y3;            // three n-vectors: y_j in buffer j % 3
+  double* PA3;           // three nwg-vectors: the workgroups' shares of q_j . y_j
   double* ab;
-  unsigned* flag;
-  unsigned base;
+  unsigned* flag;        // flag[1]: abort word
 };
 struct LzResPair { LzRes r[2]; };
 
 __device__ __forceinline__ double lz_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lz_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ bool lz_barrier_relaxed(unsigned* flag, unsigned target, long long limit, int* ok_s) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomic stores have been acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-      if (wall_clock64() - t0 > limit) {
-        __hip_atomic_store(flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    *ok_s = ok;
-  }
-  __syncthreads();
-  return *ok_s != 0;
+// "Not written yet": a quiet NaN with a payload no computation produces.  The exchange needs NO counter: a workgroup's
+// 17 words of step j go to buffer j % 3, which it has filled with this value at step j - 1 -- at a time when every
+// workgroup was done reading the buffer's previous content (that of step j - 3: read in the first phase of step j - 2, and a
+// workgroup publishes its words of step j - 2 only after that phase; seeing all of those is what lets step j - 1 begin) --
+// and whose reset it has seen acknowledged before it published step j - 1 (s_waitcnt vmcnt(0) between the two).  A reader
+// therefore finds either the mark or the word of step j, never an older word, and polls until no mark is left.
+static constexpr unsigned long long LZ_MARK_BITS = 0x7ff8a5a5deadbeefULL;
+__device__ __forceinline__ bool lz_is_mark(double v) { return (unsigned long long)__double_as_longlong(v) == LZ_MARK_BITS; }
+
+__global__ void lz_mark_kernel(double* __restrict__ p, int cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt) p[i] = __longlong_as_double((long long)LZ_MARK_BITS);
 }
 
 static constexpr int LZ_RES_MAX = 1024;       // 16 rows per lane and column
@@ -441,6 +434,7 @@ __global__ __launch_bounds__(256) void lz_resident_kernel(LzResPair args, int n,
   const LzRes& R = args.r[blockIdx.y];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int c0 = blockIdx.x * 16 + 4 * w;
+  const double mark = __longlong_as_double((long long)LZ_MARK_BITS);
   constexpr int U = LZ_RES_MAX / 64;
   double mreg[4][U];
 #pragma unroll
@@ -465,29 +459,56 @@ __global__ __launch_bounds__(256) void lz_resident_kernel(LzResPair args, int n,
       bprev = R.ab[2 * (j0 - 2) + 1];
     }
   }
+  if (t == 0) ok_s = 1;
   __syncthreads();
-  unsigned target = R.base;
+  double alpha_out = 0.0;
   for (int j = j0; j <= j1; ++j) {
     const bool finish = j == j1;            // (workgroup 0 only: alpha, beta of step j1 - 1 and q_{j1} for the host and the next launch)
     if (finish && blockIdx.x != 0) break;
     double* qs = ql + (size_t)(j % 3) * n;
     double* qj = R.Q3 + (size_t)(j % qmod) * n;
+    bool polled = true;
     if (j == 0) {
       for (int i = t; i < n; i += 256) qs[i] = qj[i];
     } else {
       const double* qm1 = ql + (size_t)((j - 1) % 3) * n;
       const double* qm2 = ql + (size_t)((j > 1 ? j - 2 : 0) % 3) * n;
-      const double* ym1 = R.Y2 + (size_t)((j + 1) & 1) * n;
-      const double* pa = R.PA2 + (size_t)((j + 1) & 1) * nwg;
-      // (the entries of y_{j-1} requested together with the partial sums: one trip to the coherent level, not two)
+      const double* ym1 = R.Y3 + (size_t)((j - 1) % 3) * n;
+      const double* pa = R.PA3 + (size_t)((j - 1) % 3) * nwg;
+      // the words of step j - 1 of every workgroup: polled until none is the mark (all requests of a poll in flight together)
       double yv[LZ_RES_MAX / 256];
-#pragma unroll
-      for (int u = 0; u < LZ_RES_MAX / 256; ++u) {
-        const int i = t + 256 * u;
-        yv[u] = i < n ? lz_ld(ym1 + i) : 0.0;
-      }
       double a = 0.0;
-      for (int e = t; e < nwg; e += 256) a += lz_ld(pa + e);
+      long long t0 = 0;
+      for (int tries = 0;; ++tries) {
+        int bad = 0;
+#pragma unroll
+        for (int u = 0; u < LZ_RES_MAX / 256; ++u) {
+          const int i = t + 256 * u;
+          yv[u] = i < n ? lz_ld(ym1 + i) : 0.0;
+        }
+        a = t < nwg ? lz_ld(pa + t) : 0.0;            // (nwg <= 64)
+#pragma unroll
+        for (int u = 0; u < LZ_RES_MAX / 256; ++u) bad |= lz_is_mark(yv[u]) ? 1 : 0;
+        bad |= lz_is_mark(a) ? 1 : 0;
+        if (tries > 0 && t == 0) {                    // bounded: the wall clock, and the other workgroups' verdict
+          if (tries == 1) t0 = wall_clock64();
+          if (__hip_atomic_load(R.flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok_s = 0;
+          else if (wall_clock64() - t0 > limit) {
+            __hip_atomic_store(R.flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok_s = 0;
+          }
+        }
+        if (!__syncthreads_or(bad)) break;
+        if (!ok_s) { polled = false; break; }
+      }
+      if (!polled) return;
+      // this workgroup's words of buffer (j + 1) % 3 back to the mark (see LZ_MARK_BITS): issued first thing -- everybody has
+      // published step j - 1, so nobody reads that buffer's old content any more --, acknowledged by the time step j is published
+      if (!finish && t < 16) {
+        const int ii = blockIdx.x * 16 + t;
+        if (ii < n) lz_st(R.Y3 + (size_t)((j + 1) % 3) * n + ii, mark);
+        if (t == 0) lz_st(R.PA3 + (size_t)((j + 1) % 3) * nwg + blockIdx.x, mark);
+      }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
       if ((t & 63) == 0) sh[t >> 6] = a;
@@ -510,16 +531,23 @@ __global__ __launch_bounds__(256) void lz_resident_kernel(LzResPair args, int n,
       __syncthreads();
       const double beta = sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
       const double r = beta > 0.0 ? 1.0 / beta : 0.0;
-      for (int i = t; i < n; i += 256) {
-        const double v = qs[i] * r;
-        qs[i] = v;
-        if (blockIdx.x == 0) qj[i] = v;
-      }
-      if (blockIdx.x == 0 && t == 0) { R.ab[2 * (j - 1)] = alpha; R.ab[2 * (j - 1) + 1] = beta; }
+      for (int i = t; i < n; i += 256) qs[i] *= r;
+      alpha_out = alpha;
       bprev = beta;
     }
+    if (j == 0 && !finish && t < 16) {      // (step 0: the marks of buffer 1; lz_resident_prepare has set them already, kept for symmetry)
+      const int ii = blockIdx.x * 16 + t;
+      if (ii < n) lz_st(R.Y3 + (size_t)n + ii, mark);
+      if (t == 0) lz_st(R.PA3 + (size_t)nwg + blockIdx.x, mark);
+    }
     __syncthreads();
-    if (finish) break;
+    if (finish) {      // (workgroup 0)
+      if (j > 0) {
+        for (int i = t; i < n; i += 256) qj[i] = qs[i];
+        if (t == 0) { R.ab[2 * (j - 1)] = alpha_out; R.ab[2 * (j - 1) + 1] = bprev; }
+      }
+      break;
+    }
     {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -539,19 +567,25 @@ __global__ __launch_bounds__(256) void lz_resident_kernel(LzResPair args, int n,
     }
     __syncthreads();
     if (t < 16) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the marks above have been acknowledged
       const double y = sh[t];
       const int ii = blockIdx.x * 16 + t;
       double d = 0.0;
       if (ii < n) {
-        lz_st(R.Y2 + (size_t)(j & 1) * n + ii, y);
+        lz_st(R.Y3 + (size_t)(j % 3) * n + ii, y);
         d = qs[ii] * y;
       }
 #pragma unroll
       for (int off = 8; off > 0; off >>= 1) d += __shfl_down(d, off, 16);
-      if (t == 0) lz_st(R.PA2 + (size_t)(j & 1) * nwg + blockIdx.x, d);
+      if (t == 0) lz_st(R.PA3 + (size_t)(j % 3) * nwg + blockIdx.x, d);
     }
-    target += (unsigned)nwg;
-    if (!lz_barrier_relaxed(R.flag, target, limit, &ok_s)) return;
+    // q_j, alpha_{j-1}, beta_{j-1} for the host and the next launch: plain stores of workgroup 0, BEHIND the publication
+    // (the wait for the marks' acknowledgement would otherwise wait for them as well, every step, with everybody waiting)
+    if (blockIdx.x == 0 && j > 0) {
+      for (int i = t; i < n; i += 256) qj[i] = qs[i];
+      if (t == 0) { R.ab[2 * (j - 1)] = alpha_out; R.ab[2 * (j - 1) + 1] = bprev; }
+    }
+    __syncthreads();      // (sh and the q ring are rewritten by the next step)
   }
 }
 
@@ -569,20 +603,26 @@ int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int q
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }
 
-// the same steps as ONE resident launch (lz_resident_kernel; n <= LZ_RES_MAX): flag = two zeroed words of the caller's
-// workspace (barrier counter, abort word), *base = barriers passed so far x workgroups (the caller keeps it across batches)
+// the same steps as ONE resident launch (lz_resident_kernel; n <= LZ_RES_MAX): Y3 / PA3 = three n- / nwg-vectors and flag =
+// two words of the caller's workspace (flag[1]: abort word), all prepared by lz_resident_prepare before the run's first step
 bool lz_resident_ok(const lrn_ctx* c, int n) {
   return c->opt.lz_resident != 0 && !c->lz_no_persist && n <= LZ_RES_MAX && n >= 32;
 }
-int lz_resident_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
-                      double* ab, unsigned* flag, unsigned* base) {
+// before the first step of a run: the three exchange buffers hold the mark, the abort word is clear
+void lz_resident_prepare(hipStream_t st, int n, double* Y3, double* PA3, unsigned* flag) {
+  const int nwg = (n + 15) / 16;
+  hipLaunchKernelGGL(lz_mark_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, st, Y3, 3 * n);
+  hipLaunchKernelGGL(lz_mark_kernel, dim3((3 * nwg + 255) / 256), dim3(256), 0, st, PA3, 3 * nwg);
+  (void)hipMemsetAsync(flag, 0, 16, st);
+}
+int lz_resident_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y3, double* PA3,
+                      double* ab, unsigned* flag) {
   if (n > LZ_RES_MAX || j1 + 1 > qcap || qcap < 3) return LRN_ERR_ARG;
   const int nwg = (n + 15) / 16;
   LzResPair a;
-  a.r[0] = LzRes{M, Q, Y2, PA2, ab, flag, *base};
+  a.r[0] = LzRes{M, Q, Y3, PA3, ab, flag};
   a.r[1] = a.r[0];
   hipLaunchKernelGGL(lz_resident_kernel, dim3(nwg, 1), dim3(256), (size_t)3 * n * 8, st, a, n, nwg, j0, j1, qcap, 2000000LL);
-  *base += (unsigned)(j1 - j0) * (unsigned)nwg;
   return hipGetLastError() == hipSuccess ? LRN_OK : LRN_ERR_HIP;
 }
 
@@ -641,6 +681,7 @@ struct LzRun {
   int nwg = 0;
   bool persist = false;                     // lz_fused_multi_kernel: a batch of steps per launch
   bool resident = false;                    // lz_resident_kernel: the same, M in registers, relaxed-atomic exchange (option lz_resident)
+  double *y3 = nullptr, *pa3 = nullptr;     // its exchange buffers (3 n, 3 nwg doubles)
   unsigned* flag = nullptr;                 // its barrier counter and abort word
   unsigned bar_base = 0;                    // barriers passed so far x nwg
 };
@@ -656,7 +697,7 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   static const bool no_fused = getenv("LRN_LZ_UNFUSED") != nullptr;
   r.fused = !no_fused && n <= LZ_FUSED_MAX && n >= 32 && ((size_t)n * 8 <= 60 * 1024 || lz_big_lds_ok());
   r.nwg = (n + 15) / 16;
-  LRN_TRY(ensure(c, buf, ((size_t)5 * n + (size_t)std::max(r.nchunk * n, 2 * r.nwg) + 2 * (size_t)r.mmax + 64) * 8));
+  LRN_TRY(ensure(c, buf, ((size_t)5 * n + (size_t)std::max(r.nchunk * n, 2 * r.nwg) + 2 * (size_t)r.mmax + 64 + 3 * (size_t)n + 3 * (size_t)r.nwg) * 8));
   r.q = buf.as<double>();                 // fused: Q3 = q[0..3n)
   r.qprev = r.q + n;
   r.w = r.q + 3 * (size_t)n;              // fused: Y2 = w[0..2n)
@@ -668,13 +709,16 @@ static int lz_begin(lrn_ctx* c, LzRun& r, const double* M, int n, hipStream_t st
   r.persist = r.fused && persist_on && !c->lz_no_persist && r.nwg <= 256 && (size_t)n * 8 <= 60 * 1024;
   r.resident = r.fused && !r.persist && c->opt.lz_resident != 0 && !c->lz_no_persist && n <= LZ_RES_MAX;
   r.flag = reinterpret_cast<unsigned*>(r.ab + 2 * (size_t)r.mmax + 8);      // (inside the 64 doubles of slack)
+  r.y3 = r.ab + 2 * (size_t)r.mmax + 64;
+  r.pa3 = r.y3 + 3 * (size_t)n;
   r.bar_base = 0;
   return LRN_OK;
 }
 
 // start vector (after lz_begin; a fresh workspace is zeroed on c->stream, which r.st must have waited for)
 static void lz_start(LzRun& r) {
-  if (r.persist || r.resident) (void)hipMemsetAsync(r.flag, 0, 16, r.st);
+  if (r.persist) (void)hipMemsetAsync(r.flag, 0, 16, r.st);
+  if (r.resident) lz_resident_prepare(r.st, r.n, r.y3, r.pa3, r.flag);
   r.bar_base = 0;
   hipLaunchKernelGGL(lz_init_kernel, dim3((r.n + 255) / 256), dim3(256), 0, r.st, r.q, r.n);
   hipLaunchKernelGGL(lz_step_kernel, dim3(1), dim3(1024), 0, r.st, r.ypart, r.nchunk, r.n, -1, r.q, r.qprev, r.w, r.ab);
@@ -685,10 +729,9 @@ static void lz_launch(LzRun& r) {
   r.m1 = std::min(r.mmax, r.m + batch);
   if (r.resident) {
     LzResPair a;
-    a.r[0] = LzRes{r.M, r.q, r.w, r.ypart, r.ab, r.flag, r.bar_base};
+    a.r[0] = LzRes{r.M, r.q, r.y3, r.pa3, r.ab, r.flag};
     a.r[1] = a.r[0];
     hipLaunchKernelGGL(lz_resident_kernel, dim3(r.nwg, 1), dim3(256), (size_t)3 * r.n * 8, r.st, a, r.n, r.nwg, r.m, r.m1, 3, 2000000LL);
-    r.bar_base += (unsigned)(r.m1 - r.m) * (unsigned)r.nwg;
     return;
   }
   if (r.fused && r.persist) {
@@ -869,9 +912,8 @@ static void lz_launch_pair(LzRun* r) {
   for (int k = 0; k < 2; ++k) { a.M[k] = r[k].M; a.Q3[k] = r[k].q; a.Y2[k] = r[k].w; a.PA2[k] = r[k].ypart; a.ab[k] = r[k].ab; }
   if (r[0].resident && r[1].resident) {
     LzResPair ra;
-    for (int k = 0; k < 2; ++k) ra.r[k] = LzRes{r[k].M, r[k].q, r[k].w, r[k].ypart, r[k].ab, r[k].flag, r[k].bar_base};
+    for (int k = 0; k < 2; ++k) ra.r[k] = LzRes{r[k].M, r[k].q, r[k].y3, r[k].pa3, r[k].ab, r[k].flag};
     hipLaunchKernelGGL(lz_resident_kernel, dim3(r[0].nwg, 2), dim3(256), (size_t)3 * n * 8, r[0].st, ra, n, r[0].nwg, m0, m1, 3, 2000000LL);
-    for (int k = 0; k < 2; ++k) r[k].bar_base += (unsigned)(m1 - m0) * (unsigned)r[k].nwg;
     r[0].m1 = r[1].m1 = m1;
     return;
   }

@@ -188,22 +188,21 @@ static int lanczos_extremes_plain(lrn_ctx* c, const double* M, int n, int k, dou
   *ok = false;
   const int mmax = std::min(n - 1, 240);
   const int nwg = (n + 15) / 16;
-  LRN_TRY(ensure(c, c->lxbuf, ((size_t)(mmax + 2) * n + 2 * (size_t)n + 2 * (size_t)nwg + 2 * (size_t)mmax + (size_t)mmax + 64) * 8));
+  LRN_TRY(ensure(c, c->lxbuf, ((size_t)(mmax + 2) * n + 3 * (size_t)n + 3 * (size_t)nwg + 2 * (size_t)mmax + (size_t)mmax + 64) * 8));
   double* Q = c->lxbuf.as<double>();
-  double* Y2 = Q + (size_t)(mmax + 2) * n;
-  double* PA2 = Y2 + 2 * (size_t)n;
-  double* ab = PA2 + 2 * (size_t)nwg;
+  double* Y2 = Q + (size_t)(mmax + 2) * n;           // (resident launches: three buffers each; launched steps use two)
+  double* PA2 = Y2 + 3 * (size_t)n;
+  double* ab = PA2 + 3 * (size_t)nwg;
   double* Sdev = ab + 2 * (size_t)mmax + 8;
   hipLaunchKernelGGL(lx_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Q, n, 0u);
   hipLaunchKernelGGL(lx_norm_kernel, dim3(1), dim3(1024), 0, st, Q, n, -1, Q, ab);
   // resident launches (ipstep.hip, lz_resident_kernel): a batch of steps per launch; two words of the workspace's slack
-  // are its barrier counter and abort word
+  // hold its abort word
   const bool resident = lz_resident_ok(c, n);
   unsigned* flag = reinterpret_cast<unsigned*>(Sdev + mmax + 8);
-  unsigned bar_base = 0;
-  if (resident) LRN_HIP(c, hipMemsetAsync(flag, 0, 16, st));
+  if (resident) lz_resident_prepare(st, n, Y2, PA2, flag);
   auto steps = [&](int j0, int j1) -> int {
-    if (resident) return lz_resident_steps(st, M, n, j0, j1, mmax + 2, Q, Y2, PA2, ab, flag, &bar_base);
+    if (resident) return lz_resident_steps(st, M, n, j0, j1, mmax + 2, Q, Y2, PA2, ab, flag);
     return lz_fused_steps(st, M, n, j0, j1, mmax + 2, Q, Y2, PA2, ab);
   };
   std::vector<double> a, b, hab, s_top, s_min;

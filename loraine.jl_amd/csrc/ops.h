@@ -46,9 +46,10 @@ int lanczos_ends(lrn_ctx* c, const double* M, int n, int nsteps, double* lo, dou
 int lz_fused_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
                    double* ab);
 static constexpr int LZ_FUSED_LIMIT = 4096;
-// the same as one resident launch per batch (option lz_resident, n <= 1024): flag = two zeroed words (barrier counter, abort
-// word; flag[1] != 0 afterwards: the launch gave up, nothing of the batch is valid), *base carried from batch to batch
+// the same as one resident launch per batch (option lz_resident, n <= 1024): Y3 / PA3 = three n- / ceil(n/16)-vectors, flag =
+// two words (flag[1] != 0 afterwards: the launch gave up, nothing of the batch is valid); lz_resident_prepare before step 0
 bool lz_resident_ok(const lrn_ctx* c, int n);
-int lz_resident_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y2, double* PA2,
-                      double* ab, unsigned* flag, unsigned* base);
+void lz_resident_prepare(hipStream_t st, int n, double* Y3, double* PA3, unsigned* flag);
+int lz_resident_steps(hipStream_t st, const double* M, int n, int j0, int j1, int qcap, double* Q, double* Y3, double* PA3,
+                      double* ab, unsigned* flag);
 }  // namespace lrn
