@@ -86,7 +86,7 @@ int lrn_get_constraint(lrn_ctx* ctx, int ilmi, int k, double* A_out);
  * pair of steps; 1 = as two launch chains on two streams; 0 = one after the other -- same results),
  * "lz_resident" (1, default: the Lanczos steps of these searches and of the H_alpha setup, matrix side <= 1024, as resident
  * launches of 16 / 24 steps -- the workgroup's columns of the matrix in registers, y and the partial dot products exchanged
- * through relaxed agent-scope atomics, a relaxed counter as the barrier, every wait bounded by the wall clock; a launch that
+ * through relaxed agent-scope atomics with no barrier (unwritten words hold a mark), every wait bounded by the wall clock; a launch that
  * gives up sends the context back to one launch per step; 0: one launch per step -- same results bit for bit),
  * "prepw_streams" (1: lrn_prepare_w runs the S side and the Gi solve on a second stream),
  * "nt_mode" (lrn_ip_prepare_w: 1 = NT scaling without singular vectors -- Newton-Schulz square roots of K = L_X'SL_X,

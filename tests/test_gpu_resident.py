@@ -49,7 +49,7 @@ def test_lanczos_eigmin(dev, n, kind):
 @pytest.mark.parametrize("n", [64, 333, 801, 1024])
 def test_resident_lanczos_steps_are_the_launched_ones(dev, n):
     """Option "lz_resident": 16 Lanczos steps per launch (the workgroup's columns of M in registers, y and the partial dot
-    products exchanged through relaxed agent-scope atomics, a relaxed counter as the barrier) against one launch per step:
+    products exchanged through relaxed agent-scope atomics, unwritten words marked, no barrier) against one launch per step:
     the same operations in the same order -- Ritz value and step count equal bit for bit, on spectra that take 30 to 400
     steps, and no launch gives up at a barrier."""
     rng = np.random.default_rng(7 * n)
@@ -141,7 +141,7 @@ def test_second_stream_changes_nothing(dev, name, opts):
     """Options "prepw_streams" (S side of prepare_W beside the SVD), "eigmin_pair" (the two Lanczos runs of a step-length
     search one after the other / as two launch chains on two streams / in lock-step, one launch per pair of steps) and
     "lz_resident" (16 Lanczos steps per launch: M in registers, the workgroups exchange y and the partial dot products
-    through relaxed agent-scope atomics and meet at a relaxed counter): the same arithmetic on the same data in the same
+    through relaxed agent-scope atomics, unwritten words marked): the same arithmetic on the same data in the same
     order -- every iteration's objectives are bit-identical in all forms, and the forms are really taken."""
     path = os.path.join(GOLD, f"{name}.dat-s")
     runs = []
